@@ -1,0 +1,66 @@
+"""Build libirmv_hip.so (gfx950) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only container; the
+resulting .so is git-ignored but travels to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libirmv_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+# (source, extra flags).  k_post.hip must not contract a*b+c: see its header.
+SOURCES = [
+    ("k_pre.hip", []),
+    ("k_conv.hip", []),
+    ("k_post.hip", ["-ffp-contract=off"]),
+    ("engine.cpp", ["-x", "hip"]),
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
+          "-I", INCLUDE]
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, "irmv_common.hpp"), os.path.join(INCLUDE, "irmv_hip.h"), __file__]
+    objs = []
+    cc = hipcc()
+    for src, extra in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        if force or _stale(obj, [sp] + headers):
+            cmd = [cc] + COMMON + extra + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=False, verbose=True))

@@ -1,0 +1,131 @@
+"""ctypes binding of include/irmv_hip.h (libirmv_hip.so).
+
+Thin by design: every function here is one C-ABI call.  There is no fallback of
+any kind -- if the HIP library is missing or a call fails, IrmvError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+OK, ERR_ARG, ERR_HIP, ERR_MODEL, ERR_OVERFLOW = 0, -1, -2, -3, -4
+RESIZE_STRETCH, RESIZE_LETTERBOX = 0, 1
+ARMOR_SMALL, ARMOR_LARGE = 0, 1
+SUBMIT_H2D = 1
+NUM_CLASSES = 14
+MAX_DET_CAP = 256
+CAND_CAP = 8192
+
+
+class IrmvError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"irmv_hip error {code}: {msg}")
+        self.code = code
+
+
+class EngineCfg(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32),
+        ("src_width", C.c_int32), ("src_height", C.c_int32), ("net_size", C.c_int32),
+        ("resize_mode", C.c_int32), ("rotate180", C.c_int32), ("swap_rb", C.c_int32),
+        ("score_thr", C.c_float), ("iou_thr", C.c_float),
+        ("max_det", C.c_int32), ("pre_nms_cap", C.c_int32), ("num_slots", C.c_int32),
+        ("armor_size", C.c_int32),
+        ("camera_matrix", C.c_double * 9), ("dist_coeffs", C.c_double * 5),
+        ("weights_path", C.c_char_p), ("weights_blob", C.c_void_p), ("weights_bytes", C.c_uint64),
+        ("weights_on_device", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Det(C.Structure):
+    _fields_ = [
+        ("xyxy", C.c_float * 4), ("score", C.c_float), ("class_id", C.c_int32),
+        ("anchor", C.c_int32), ("pnp_ok", C.c_int32), ("kpts", C.c_float * 8),
+        ("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("quat", C.c_double * 4),
+    ]
+
+
+class RawDets(C.Structure):
+    _fields_ = [
+        ("num_dets", C.c_int32), ("n_candidates", C.c_int32),
+        ("det_boxes", C.POINTER(C.c_float)), ("det_scores", C.POINTER(C.c_float)),
+        ("det_classes", C.POINTER(C.c_int32)), ("det_anchors", C.POINTER(C.c_int32)),
+        ("det_kpts", C.POINTER(C.c_float)),
+    ]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("layer", C.c_char * 32), ("flops", C.c_double),
+                ("bytes", C.c_double), ("ms", C.c_float), ("reserved", C.c_int32)]
+
+
+# every symbol include/irmv_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("irmv_last_error", C.c_char_p, []),
+    ("irmv_version", C.c_char_p, []),
+    ("irmv_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("irmv_engine_cfg_default", None, [C.POINTER(EngineCfg)]),
+    ("irmv_engine_create", C.c_int, [C.POINTER(EngineCfg), C.POINTER(_P)]),
+    ("irmv_engine_destroy", None, [_P]),
+    ("irmv_engine_num_slots", C.c_int, [_P]),
+    ("irmv_engine_max_det", C.c_int, [_P]),
+    ("irmv_engine_src_buffer", C.POINTER(C.c_uint8), [_P, C.c_int]),
+    ("irmv_engine_src_device_buffer", C.c_void_p, [_P, C.c_int]),
+    ("irmv_engine_submit", C.c_int, [_P, C.c_int, C.c_int, C.c_uint32]),
+    ("irmv_engine_wait", C.c_int, [_P]),
+    ("irmv_engine_results", C.c_int, [_P, C.c_int, C.POINTER(Det), C.c_int, C.POINTER(C.c_int)]),
+    ("irmv_engine_detect", C.c_int, [_P, C.c_int, C.POINTER(Det), C.c_int, C.POINTER(C.c_int)]),
+    ("irmv_engine_last_detect_ms", C.c_double, [_P]),
+    ("irmv_engine_rotated_image", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint8)]),
+    ("irmv_engine_read_input", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    ("irmv_engine_read_head", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    ("irmv_engine_write_head", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    ("irmv_engine_run_post", C.c_int, [_P, C.c_int, C.c_int]),
+    ("irmv_engine_read_tap", C.c_int, [_P, C.c_int, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    ("irmv_engine_read_raw", C.c_int, [_P, C.c_int, C.POINTER(RawDets)]),
+    ("irmv_engine_num_anchors", C.c_int, [_P]),
+    ("irmv_engine_head_channels", C.c_int, [_P]),
+    ("irmv_engine_profile", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),
+    ("irmv_pnp_create", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_P)]),
+    ("irmv_pnp_destroy", None, [_P]),
+    ("irmv_pnp_solve", C.c_int, [_P, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+]
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libirmv_hip.so (must have been built in-tree; see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise IrmvError(ERR_HIP, f"{path} is missing: build the HIP extension first "
+                                     "(python -m irmv_detection_amd._build); there is no CPU fallback")
+        L = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, allow=()):
+    if rc != OK and rc not in allow:
+        raise IrmvError(rc, load().irmv_last_error().decode(errors="replace"))
+    return rc
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load().irmv_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,1012 @@
+// libirmv_hip.so host side: engine object, execution plan, hipGraph capture, C ABI.
+//
+// MI355X-first counterpart of irmv_detection::YoloEngine (reference
+// src/yolo_engine.cpp) and PnPSolver (src/pnp_solver.cpp):
+//   * frame slots are pinned host memory (hipHostMalloc) copied to HBM by an
+//     async memcpy node of the captured step -- the dGPU answer to the
+//     reference's cudaMallocManaged source buffer (:60-61) + TripleBuffer;
+//   * one set of weights per device shared by all slots (the reference builds
+//     three full engines, src/irm_detector.cpp:35-38);
+//   * the whole step {H2D, preprocess, ~73 conv launches, pool, decode, NMS+PnP,
+//     D2H} is captured once per (first_slot, count) into a hipGraph (:102-107)
+//     and `count` independent frames ride through every kernel as the batch
+//     dimension of its GEMM M axis, which is what fills 256 CUs;
+//   * no host work between launch and results except the final struct copy
+//     (parse_output's scaling, :202-220, runs in the NMS kernel).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/irmv_hip.h"
+#include "irmv_common.hpp"
+
+using namespace irmv;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(IRMV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+extern "C" const char *irmv_last_error(void) { return g_err.c_str(); }
+extern "C" const char *irmv_version(void) { return "irmv_hip 0.1 (gfx950)"; }
+extern "C" int irmv_device_count(int *count)
+{
+    if (!count) return fail(IRMV_ERR_ARG, "count is null");
+    HIP_TRY(hipGetDeviceCount(count));
+    return IRMV_OK;
+}
+
+// ---- .irmw blob ------------------------------------------------------------------
+#pragma pack(push, 1)
+struct BlobHeader { char magic[4]; uint32_t version, nc, nk, reg_max, n_layers, dtype, reserved; };
+struct BlobLayer { char name[32]; uint32_t cin, cout, k, stride, act, pad; uint64_t w_off, b_off; };
+#pragma pack(pop)
+
+struct LayerW {
+    std::string name;
+    int cin, cout, k, stride, act;
+    const uint16_t *w;  // OHWI fp16 bits (points into the blob copy)
+    const float *b;
+};
+
+static float half_bits_to_float(uint16_t h)
+{
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, x;
+    if (exp == 0) {
+        if (man == 0) x = sign;
+        else {
+            int e = -1;
+            do { e++; man <<= 1; } while (!(man & 0x400u));
+            x = sign | ((uint32_t)(112 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) x = sign | 0x7f800000u | (man << 13);
+    else x = sign | ((exp + 112u) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+// ---- engine ----------------------------------------------------------------------
+struct Tensor {
+    std::string name;
+    void *base = nullptr;
+    size_t slot_elems = 0;
+    int H = 0, W = 0, C = 0;
+    bool f32 = false;
+    size_t esize() const { return f32 ? 4 : 2; }
+    void *slot(int s) const { return static_cast<char *>(base) + (size_t)s * slot_elems * esize(); }
+};
+
+struct SegRef { int t = -1, coff = 0, C = 0, shift = 0; };
+
+enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_DECODE, OP_NMS };
+
+struct Op {
+    OpKind kind;
+    std::string layer;
+    ConvCfg cfg{};
+    SegRef s0, s1;
+    int Hin = 0, Win = 0, Hout = 0, Wout = 0, cin = 0, cout = 0, cout_pad = 0, ksteps = 0;
+    int out_t = -1, out_coff = 0, res_t = -1, res_coff = 0;
+    half_t *w_packed = nullptr;
+    float *bias = nullptr;
+    double flops = 0, bytes = 0;  // per frame
+    char kname[48] = {0};
+};
+
+struct GraphKey {
+    int first, count;
+    uint32_t flags;
+    bool operator<(const GraphKey &o) const
+    {
+        return std::tie(first, count, flags) < std::tie(o.first, o.count, o.flags);
+    }
+};
+
+struct irmv_engine {
+    irmv_engine_cfg cfg{};
+    int nc = 0, nk = 0, A = 0, no = 0;
+    int lvl_hw[3] = {0, 0, 0}, lvl_base[3] = {0, 0, 0};
+    size_t frame_bytes = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *src_host = nullptr;  // pinned [S][frame]
+    uint8_t *src_dev = nullptr;   // [S][frame]
+    uint8_t *rot_dev = nullptr;   // [frame]
+    AxisTap *tap_x = nullptr, *tap_y = nullptr;
+    std::vector<Tensor> tensors;
+    std::map<std::string, int> tensor_idx;
+    std::vector<Op> ops;
+    std::vector<void *> dev_allocs;
+    int head_t[3] = {-1, -1, -1};
+    float *boxes = nullptr;
+    unsigned long long *keys = nullptr;
+    int *counts = nullptr;
+    DevDet *dets_dev = nullptr, *dets_host = nullptr;
+    DevFrameOut *fout_dev = nullptr, *fout_host = nullptr;
+    float *conv0_w = nullptr, *conv0_b = nullptr;
+    PostArgs post{};
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    double last_detect_ms = 0;
+    std::vector<uint8_t> blob;
+    std::vector<LayerW> layers;
+
+    ~irmv_engine();
+};
+
+irmv_engine::~irmv_engine()
+{
+    if (cfg.device >= 0) (void)hipSetDevice(cfg.device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
+    for (void *p : dev_allocs) (void)hipFree(p);
+    if (src_host) (void)hipHostFree(src_host);
+    if (dets_host) (void)hipHostFree(dets_host);
+    if (fout_host) (void)hipHostFree(fout_host);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+static int dev_alloc(irmv_engine *e, void **p, size_t bytes)
+{
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    e->dev_allocs.push_back(*p);
+    return IRMV_OK;
+}
+
+static int new_tensor(irmv_engine *e, const std::string &name, int H, int W, int C, bool f32, int *idx)
+{
+    Tensor t;
+    t.name = name;
+    t.H = H; t.W = W; t.C = C; t.f32 = f32;
+    t.slot_elems = (size_t)H * W * C;
+    int rc = dev_alloc(e, &t.base, t.slot_elems * t.esize() * e->cfg.num_slots);
+    if (rc) return rc;
+    // activations start at zero so that never-written pad channels are finite
+    HIP_TRY(hipMemset(t.base, 0, t.slot_elems * t.esize() * e->cfg.num_slots));
+    *idx = (int)e->tensors.size();
+    e->tensor_idx[name] = *idx;
+    e->tensors.push_back(t);
+    return IRMV_OK;
+}
+
+static const LayerW *find_layer(const irmv_engine *e, const std::string &name)
+{
+    for (auto &l : e->layers)
+        if (l.name == name) return &l;
+    return nullptr;
+}
+
+// output channel held by row p of 16-row MFMA tile t (see k_conv.hip epilogue)
+static int tile_row_cout(int t, int p, bool pair)
+{
+    if (!pair) return t * 16 + p;
+    return (t >> 1) * 32 + (p >> 2) * 8 + (t & 1) * 4 + (p & 3);
+}
+
+static int pack_conv(irmv_engine *e, const LayerW &l, Op &op)
+{
+    const int taps = l.k * l.k;
+    op.cout_pad = (l.cout + 15) / 16 * 16;
+    const int ntiles = op.cout_pad / 16;
+    const bool pair = !op.cfg.out_f32 && (op.cfg.nt % 2 == 0);
+    const int cpt = (l.cin + 31) / 32;
+    op.ksteps = op.cfg.cin16 ? (taps + 1) / 2 : taps * cpt;
+    std::vector<uint16_t> packed((size_t)ntiles * op.ksteps * 512, 0);
+    for (int t = 0; t < ntiles; t++)
+        for (int ks = 0; ks < op.ksteps; ks++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int g = lane >> 4, r = lane & 15;
+                const int co = tile_row_cout(t, r, pair);
+                for (int j = 0; j < 8; j++) {
+                    int tap, c;
+                    if (op.cfg.cin16) { tap = 2 * ks + (g >> 1); c = 8 * (g & 1) + j; }
+                    else { tap = ks / cpt; c = (ks % cpt) * 32 + 8 * g + j; }
+                    uint16_t v = 0;
+                    if (co < l.cout && tap < taps && c < l.cin) v = l.w[((size_t)co * taps + tap) * l.cin + c];
+                    packed[(((size_t)t * op.ksteps + ks) * 64 + lane) * 8 + j] = v;
+                }
+            }
+    std::vector<float> bias(op.cout_pad, 0.f);
+    for (int i = 0; i < l.cout; i++) bias[i] = l.b[i];
+    int rc = dev_alloc(e, (void **)&op.w_packed, packed.size() * 2);
+    if (rc) return rc;
+    rc = dev_alloc(e, (void **)&op.bias, bias.size() * 4);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(op.w_packed, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(op.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    return IRMV_OK;
+}
+
+static int add_conv(irmv_engine *e, const std::string &layer, SegRef s0, SegRef s1, int Hin, int Win, int out_t,
+                    int out_coff, int res_t = -1, int res_coff = 0)
+{
+    const LayerW *l = find_layer(e, layer);
+    if (!l) return fail(IRMV_ERR_MODEL, "weight blob has no layer " + layer);
+    if (l->cin != s0.C + s1.C) return fail(IRMV_ERR_MODEL, "layer " + layer + ": cin does not match the graph");
+    Op op;
+    op.kind = OP_CONV;
+    op.layer = layer;
+    op.s0 = s0; op.s1 = s1;
+    op.Hin = Hin; op.Win = Win;
+    op.Hout = Hin / l->stride; op.Wout = Win / l->stride;
+    op.cin = l->cin; op.cout = l->cout;
+    op.out_t = out_t; op.out_coff = out_coff; op.res_t = res_t; op.res_coff = res_coff;
+    const Tensor &ot = e->tensors[out_t];
+    if (ot.H != op.Hout || ot.W != op.Wout) return fail(IRMV_ERR_MODEL, "layer " + layer + ": output shape mismatch");
+    const int cout_pad = (l->cout + 15) / 16 * 16;
+    if (out_coff + cout_pad > ot.C) return fail(IRMV_ERR_MODEL, "layer " + layer + ": output slice out of range");
+    op.cfg.ks = l->k; op.cfg.stride = l->stride; op.cfg.act = l->act; op.cfg.out_f32 = ot.f32;
+    op.cfg.cin16 = (l->cin == 16 && l->k == 3);
+    const int nt_all = cout_pad / 16;
+    op.cfg.nt = nt_all >= 4 ? 4 : nt_all;
+    // enough workgroups to cover 256 CUs a few times, else halve the pixel tile
+    const long m_batch = (long)e->cfg.num_slots * op.Hout * op.Wout;
+    const long blocks_mt2 = ((m_batch + 127) / 128) * (cout_pad / (16 * op.cfg.nt));
+    op.cfg.mt = blocks_mt2 >= 512 ? 2 : 1;
+    conv_cfg_name(op.cfg, op.kname, sizeof op.kname);
+    op.flops = 2.0 * op.Hout * op.Wout * (double)l->cout * l->cin * l->k * l->k;
+    op.bytes = 2.0 * ((double)Hin * Win * l->cin / ((s0.shift || s1.shift) ? 1.0 : 1.0)) +
+               (double)op.Hout * op.Wout * l->cout * (ot.f32 ? 4.0 : 2.0) + 2.0 * l->cout * l->cin * l->k * l->k;
+    int rc = pack_conv(e, *l, op);
+    if (rc) return rc;
+    e->ops.push_back(op);
+    return IRMV_OK;
+}
+
+#define TRY(x)            \
+    do {                  \
+        int _rc = (x);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+static int add_c2f(irmv_engine *e, const std::string &prefix, SegRef s0, SegRef s1, int H, int W, int c2, int n,
+                   bool shortcut, int out_t)
+{
+    const int c = c2 / 2;
+    int cat, tmp;
+    TRY(new_tensor(e, prefix + ".cat", H, W, (2 + n) * c, false, &cat));
+    TRY(new_tensor(e, prefix + ".tmp", H, W, c, false, &tmp));
+    TRY(add_conv(e, prefix + ".cv1", s0, s1, H, W, cat, 0));
+    for (int i = 0; i < n; i++) {
+        const std::string m = prefix + ".m." + std::to_string(i);
+        TRY(add_conv(e, m + ".cv1", SegRef{cat, (1 + i) * c, c, 0}, SegRef{}, H, W, tmp, 0));
+        TRY(add_conv(e, m + ".cv2", SegRef{tmp, 0, c, 0}, SegRef{}, H, W, cat, (2 + i) * c, shortcut ? cat : -1,
+                     (1 + i) * c));
+    }
+    TRY(add_conv(e, prefix + ".cv2", SegRef{cat, 0, (2 + n) * c, 0}, SegRef{}, H, W, out_t, 0));
+    return IRMV_OK;
+}
+
+// integer tap geometry: same arithmetic as the oracle's axis_tap, written independently
+static void axis_taps(std::vector<AxisTap> &out, int dn_total, int sn, int dn, int pad, bool rotate)
+{
+    out.assign(dn_total, AxisTap{-1, -1, 0, 0});
+    for (int d = 0; d < dn_total; d++) {
+        const int r = d - pad;
+        if (r < 0 || r >= dn) continue;
+        const long long num = (long long)(2 * r + 1) * sn - dn, den = 2LL * dn;
+        const long long fl = num >= 0 ? num / den : -((-num + den - 1) / den);
+        const long long frac = num - fl * den;
+        int w = (int)((frac * 2048 + dn) / den);
+        int a = (int)fl, b = a + 1;
+        if (a < 0) { a = 0; b = 0; w = 0; }
+        if (a >= sn - 1) { a = sn - 1; b = sn - 1; w = 0; }
+        if (rotate) { a = sn - 1 - a; b = sn - 1 - b; }
+        out[d] = AxisTap{a, b, w, 0};
+    }
+}
+
+static int build_engine(irmv_engine *e)
+{
+    const irmv_engine_cfg &c = e->cfg;
+    const int net = c.net_size, S = c.num_slots;
+    HIP_TRY(hipSetDevice(c.device));
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->frame_bytes = (size_t)c.src_width * c.src_height * 3;
+    HIP_TRY(hipHostMalloc((void **)&e->src_host, e->frame_bytes * S, hipHostMallocDefault));
+    memset(e->src_host, 0, e->frame_bytes * S);
+    TRY(dev_alloc(e, (void **)&e->src_dev, e->frame_bytes * S));
+    HIP_TRY(hipMemset(e->src_dev, 0, e->frame_bytes * S));
+    TRY(dev_alloc(e, (void **)&e->rot_dev, e->frame_bytes));
+
+    // ---- preprocess geometry (parse_output inverse mapping) ----
+    int nw = net, nh = net, px = 0, py = 0;
+    if (c.resize_mode == IRMV_RESIZE_LETTERBOX) {
+        const double r = std::min((double)net / c.src_width, (double)net / c.src_height);
+        nw = std::min(net, (int)std::floor(c.src_width * r + 0.5));
+        nh = std::min(net, (int)std::floor(c.src_height * r + 0.5));
+        px = (net - nw) / 2;
+        py = (net - nh) / 2;
+    }
+    std::vector<AxisTap> tx, ty;
+    axis_taps(tx, net, c.src_width, nw, px, c.rotate180 != 0);
+    axis_taps(ty, net, c.src_height, nh, py, c.rotate180 != 0);
+    TRY(dev_alloc(e, (void **)&e->tap_x, net * sizeof(AxisTap)));
+    TRY(dev_alloc(e, (void **)&e->tap_y, net * sizeof(AxisTap)));
+    HIP_TRY(hipMemcpy(e->tap_x, tx.data(), net * sizeof(AxisTap), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->tap_y, ty.data(), net * sizeof(AxisTap), hipMemcpyHostToDevice));
+
+    // ---- graph ----
+    const int s2 = net / 2, s4 = net / 4, s8 = net / 8, s16 = net / 16, s32 = net / 32;
+    int x0, a0, a1, a2, a3, a4, a5, a6, a7, a8, s9, a9, a12, a15, a16, a18, a19, a21;
+    TRY(new_tensor(e, "input", net, net, 4, false, &x0));
+    TRY(new_tensor(e, "0", s2, s2, 16, false, &a0));
+    TRY(new_tensor(e, "1", s4, s4, 32, false, &a1));
+    TRY(new_tensor(e, "2", s4, s4, 32, false, &a2));
+    TRY(new_tensor(e, "3", s8, s8, 64, false, &a3));
+    TRY(new_tensor(e, "4", s8, s8, 64, false, &a4));
+    TRY(new_tensor(e, "5", s16, s16, 128, false, &a5));
+    TRY(new_tensor(e, "6", s16, s16, 128, false, &a6));
+    TRY(new_tensor(e, "7", s32, s32, 256, false, &a7));
+    TRY(new_tensor(e, "8", s32, s32, 256, false, &a8));
+    TRY(new_tensor(e, "9.cat", s32, s32, 512, false, &s9));
+    TRY(new_tensor(e, "9", s32, s32, 256, false, &a9));
+    TRY(new_tensor(e, "12", s16, s16, 128, false, &a12));
+    TRY(new_tensor(e, "15", s8, s8, 64, false, &a15));
+    TRY(new_tensor(e, "16", s16, s16, 64, false, &a16));
+    TRY(new_tensor(e, "18", s16, s16, 128, false, &a18));
+    TRY(new_tensor(e, "19", s32, s32, 128, false, &a19));
+    TRY(new_tensor(e, "21", s32, s32, 256, false, &a21));
+
+    { Op op; op.kind = OP_PRE; op.layer = "preprocess"; snprintf(op.kname, sizeof op.kname, "preprocess");
+      op.bytes = (double)e->frame_bytes + (double)net * net * 8; e->ops.push_back(op); }
+    {
+        const LayerW *l = find_layer(e, "model.0.conv");
+        if (!l || l->cin != 3 || l->cout != 16 || l->k != 3 || l->stride != 2)
+            return fail(IRMV_ERR_MODEL, "model.0.conv missing or not 3x3 s2 3->16");
+        std::vector<float> w(27 * 16), b(16);
+        for (int o = 0; o < 16; o++) {
+            b[o] = l->b[o];
+            for (int t = 0; t < 9; t++)
+                for (int ci = 0; ci < 3; ci++) w[(t * 3 + ci) * 16 + o] = half_bits_to_float(l->w[(o * 9 + t) * 3 + ci]);
+        }
+        TRY(dev_alloc(e, (void **)&e->conv0_w, w.size() * 4));
+        TRY(dev_alloc(e, (void **)&e->conv0_b, b.size() * 4));
+        HIP_TRY(hipMemcpy(e->conv0_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->conv0_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        Op op; op.kind = OP_CONV0; op.layer = "model.0.conv"; snprintf(op.kname, sizeof op.kname, "conv0_valu");
+        op.flops = 2.0 * s2 * s2 * 16 * 27;
+        op.bytes = (double)net * net * 8 + (double)s2 * s2 * 32 + 27 * 16 * 2;
+        e->ops.push_back(op);
+    }
+    TRY(add_conv(e, "model.1.conv", SegRef{a0, 0, 16, 0}, SegRef{}, s2, s2, a1, 0));
+    TRY(add_c2f(e, "model.2", SegRef{a1, 0, 32, 0}, SegRef{}, s4, s4, 32, 1, true, a2));
+    TRY(add_conv(e, "model.3.conv", SegRef{a2, 0, 32, 0}, SegRef{}, s4, s4, a3, 0));
+    TRY(add_c2f(e, "model.4", SegRef{a3, 0, 64, 0}, SegRef{}, s8, s8, 64, 2, true, a4));
+    TRY(add_conv(e, "model.5.conv", SegRef{a4, 0, 64, 0}, SegRef{}, s8, s8, a5, 0));
+    TRY(add_c2f(e, "model.6", SegRef{a5, 0, 128, 0}, SegRef{}, s16, s16, 128, 2, true, a6));
+    TRY(add_conv(e, "model.7.conv", SegRef{a6, 0, 128, 0}, SegRef{}, s16, s16, a7, 0));
+    TRY(add_c2f(e, "model.8", SegRef{a7, 0, 256, 0}, SegRef{}, s32, s32, 256, 1, true, a8));
+    TRY(add_conv(e, "model.9.cv1", SegRef{a8, 0, 256, 0}, SegRef{}, s32, s32, s9, 0));
+    { Op op; op.kind = OP_POOL; op.layer = "model.9.m"; snprintf(op.kname, sizeof op.kname, "sppf_pool");
+      op.bytes = (double)s32 * s32 * 128 * 2 * 4; e->ops.push_back(op); }
+    TRY(add_conv(e, "model.9.cv2", SegRef{s9, 0, 512, 0}, SegRef{}, s32, s32, a9, 0));
+    TRY(add_c2f(e, "model.12", SegRef{a9, 0, 256, 1}, SegRef{a6, 0, 128, 0}, s16, s16, 128, 1, false, a12));
+    TRY(add_c2f(e, "model.15", SegRef{a12, 0, 128, 1}, SegRef{a4, 0, 64, 0}, s8, s8, 64, 1, false, a15));
+    TRY(add_conv(e, "model.16.conv", SegRef{a15, 0, 64, 0}, SegRef{}, s8, s8, a16, 0));
+    TRY(add_c2f(e, "model.18", SegRef{a16, 0, 64, 0}, SegRef{a12, 0, 128, 0}, s16, s16, 128, 1, false, a18));
+    TRY(add_conv(e, "model.19.conv", SegRef{a18, 0, 128, 0}, SegRef{}, s16, s16, a19, 0));
+    TRY(add_c2f(e, "model.21", SegRef{a19, 0, 128, 0}, SegRef{a9, 0, 256, 0}, s32, s32, 256, 1, false, a21));
+
+    // Detect head: per level one fp32 record of kHeadRec per anchor: box 64 | cls 16 | kpt 16
+    const int P[3] = {a15, a18, a21}, PC[3] = {64, 128, 256}, PS[3] = {s8, s16, s32};
+    int base = 0;
+    for (int i = 0; i < 3; i++) {
+        e->lvl_hw[i] = PS[i] * PS[i];
+        e->lvl_base[i] = base;
+        base += e->lvl_hw[i];
+        TRY(new_tensor(e, "head." + std::to_string(i), PS[i], PS[i], kHeadRec, true, &e->head_t[i]));
+    }
+    e->A = base;
+    const char *br[3] = {"cv2", "cv3", "cv4"};
+    const int mid[3] = {64, 64, 16}, off[3] = {0, kClsOff, kKptOff};
+    for (int b = 0; b < (e->nk > 0 ? 3 : 2); b++)
+        for (int i = 0; i < 3; i++) {
+            const std::string pre = std::string("model.22.") + br[b] + "." + std::to_string(i);
+            const std::string tn = std::string("22.") + br[b] + "." + std::to_string(i);
+            int t1, t2;
+            TRY(new_tensor(e, tn + ".0", PS[i], PS[i], mid[b], false, &t1));
+            TRY(new_tensor(e, tn + ".1", PS[i], PS[i], mid[b], false, &t2));
+            TRY(add_conv(e, pre + ".0", SegRef{P[i], 0, PC[i], 0}, SegRef{}, PS[i], PS[i], t1, 0));
+            TRY(add_conv(e, pre + ".1", SegRef{t1, 0, mid[b], 0}, SegRef{}, PS[i], PS[i], t2, 0));
+            TRY(add_conv(e, pre + ".2", SegRef{t2, 0, mid[b], 0}, SegRef{}, PS[i], PS[i], e->head_t[i], off[b]));
+        }
+
+    // ---- post-processing buffers ----
+    TRY(dev_alloc(e, (void **)&e->boxes, (size_t)S * e->A * 16));
+    TRY(dev_alloc(e, (void **)&e->keys, (size_t)S * kCandCap * 8));
+    TRY(dev_alloc(e, (void **)&e->counts, (size_t)S * 4));
+    HIP_TRY(hipMemset(e->counts, 0, (size_t)S * 4));
+    TRY(dev_alloc(e, (void **)&e->dets_dev, (size_t)S * c.max_det * sizeof(DevDet)));
+    TRY(dev_alloc(e, (void **)&e->fout_dev, (size_t)S * sizeof(DevFrameOut)));
+    HIP_TRY(hipMemset(e->dets_dev, 0, (size_t)S * c.max_det * sizeof(DevDet)));
+    HIP_TRY(hipMemset(e->fout_dev, 0, (size_t)S * sizeof(DevFrameOut)));
+    HIP_TRY(hipHostMalloc((void **)&e->dets_host, (size_t)S * c.max_det * sizeof(DevDet), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&e->fout_host, (size_t)S * sizeof(DevFrameOut), hipHostMallocDefault));
+    memset(e->dets_host, 0, (size_t)S * c.max_det * sizeof(DevDet));
+    memset(e->fout_host, 0, (size_t)S * sizeof(DevFrameOut));
+    { Op op; op.kind = OP_DECODE; op.layer = "decode"; snprintf(op.kname, sizeof op.kname, "decode");
+      op.bytes = (double)e->A * (kHeadRec * 4 + 16); e->ops.push_back(op); }
+    { Op op; op.kind = OP_NMS; op.layer = "nms_kpt_pnp"; snprintf(op.kname, sizeof op.kname, "nms_pnp"); e->ops.push_back(op); }
+
+    PostArgs &p = e->post;
+    p.net = net; p.A = e->A; p.nc = e->nc; p.nk = e->nk;
+    p.logit_thr = (float)std::log((double)c.score_thr / (1.0 - (double)c.score_thr));
+    p.iou_thr = c.iou_thr;
+    p.max_det = c.max_det;
+    p.pre_nms_cap = c.pre_nms_cap;
+    if (c.resize_mode == IRMV_RESIZE_STRETCH) {
+        p.scale_x = (float)c.src_width / (float)net;   // src/yolo_engine.cpp:155-156
+        p.scale_y = (float)c.src_height / (float)net;
+        p.off_x = p.off_y = 0.f;
+    } else {
+        p.scale_x = (float)c.src_width / (float)nw;
+        p.scale_y = (float)c.src_height / (float)nh;
+        p.off_x = (float)px;
+        p.off_y = (float)py;
+    }
+    p.armor_size = c.armor_size;
+    p.pnp.fx = c.camera_matrix[0]; p.pnp.fy = c.camera_matrix[4];
+    p.pnp.cx = c.camera_matrix[2]; p.pnp.cy = c.camera_matrix[5];
+    p.pnp.k1 = c.dist_coeffs[0]; p.pnp.k2 = c.dist_coeffs[1]; p.pnp.p1 = c.dist_coeffs[2];
+    p.pnp.p2 = c.dist_coeffs[3]; p.pnp.k3 = c.dist_coeffs[4];
+    p.pnp.hy[0] = 135.0 / 2.0 / 1000.0; p.pnp.hy[1] = 225.0 / 2.0 / 1000.0;   // src/pnp_solver.cpp:18-21
+    p.pnp.hz[0] = p.pnp.hz[1] = 55.0 / 2.0 / 1000.0;
+    HIP_TRY(hipDeviceSynchronize());
+    return IRMV_OK;
+}
+
+static int load_blob(irmv_engine *e)
+{
+    const irmv_engine_cfg &c = e->cfg;
+    if (c.weights_path) {
+        std::string path = c.weights_path;
+        const size_t dot = path.find_last_of('.');
+        if (dot != std::string::npos && path.substr(dot) != ".irmw") path = path.substr(0, dot) + ".irmw";
+        std::ifstream f(path, std::ios::binary);
+        if (!f) return fail(IRMV_ERR_MODEL, "cannot open weight blob " + path + " (convert the model to .irmw first)");
+        f.seekg(0, std::ios::end);
+        const size_t n = (size_t)f.tellg();
+        f.seekg(0, std::ios::beg);
+        e->blob.resize(n);
+        f.read(reinterpret_cast<char *>(e->blob.data()), (std::streamsize)n);
+    } else if (c.weights_blob && c.weights_bytes) {
+        e->blob.resize(c.weights_bytes);
+        if (c.weights_on_device) {
+            HIP_TRY(hipSetDevice(c.device));
+            HIP_TRY(hipMemcpy(e->blob.data(), c.weights_blob, c.weights_bytes, hipMemcpyDeviceToHost));
+        } else {
+            memcpy(e->blob.data(), c.weights_blob, c.weights_bytes);
+        }
+    } else {
+        return fail(IRMV_ERR_MODEL, "no weights: set weights_path or weights_blob");
+    }
+    if (e->blob.size() < sizeof(BlobHeader)) return fail(IRMV_ERR_MODEL, "weight blob truncated");
+    BlobHeader h;
+    memcpy(&h, e->blob.data(), sizeof h);
+    if (memcmp(h.magic, "IRMW", 4) != 0 || h.version != 1 || h.dtype != 1 || h.reg_max != 16)
+        return fail(IRMV_ERR_MODEL, "not an IRMW v1 fp16 blob");
+    if (h.nc < 1 || h.nc > 16 || (h.nk != 0 && h.nk != 8))
+        return fail(IRMV_ERR_MODEL, "unsupported head: nc must be 1..16, nk 0 or 8");
+    e->nc = (int)h.nc;
+    e->nk = (int)h.nk;
+    e->no = 64 + e->nc + e->nk;
+    if (sizeof h + (size_t)h.n_layers * sizeof(BlobLayer) > e->blob.size()) return fail(IRMV_ERR_MODEL, "layer table truncated");
+    for (uint32_t i = 0; i < h.n_layers; i++) {
+        BlobLayer bl;
+        memcpy(&bl, e->blob.data() + sizeof h + (size_t)i * sizeof bl, sizeof bl);
+        LayerW l;
+        char nm[33];
+        memcpy(nm, bl.name, 32);
+        nm[32] = 0;
+        l.name = nm;
+        l.cin = bl.cin; l.cout = bl.cout; l.k = bl.k; l.stride = bl.stride; l.act = bl.act;
+        const size_t nw = (size_t)l.cout * l.k * l.k * l.cin;
+        if (bl.w_off + nw * 2 > e->blob.size() || bl.b_off + (size_t)l.cout * 4 > e->blob.size())
+            return fail(IRMV_ERR_MODEL, "layer " + l.name + " data out of range");
+        l.w = reinterpret_cast<const uint16_t *>(e->blob.data() + bl.w_off);
+        l.b = reinterpret_cast<const float *>(e->blob.data() + bl.b_off);
+        e->layers.push_back(l);
+    }
+    return IRMV_OK;
+}
+
+extern "C" void irmv_engine_cfg_default(irmv_engine_cfg *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->device = 0;
+    cfg->src_width = 1280;
+    cfg->src_height = 1024;
+    cfg->net_size = 640;
+    cfg->resize_mode = IRMV_RESIZE_STRETCH;
+    cfg->rotate180 = 1;
+    cfg->swap_rb = 0;
+    cfg->score_thr = 0.25f;
+    cfg->iou_thr = 0.45f;
+    cfg->max_det = 100;
+    cfg->pre_nms_cap = 4096;
+    cfg->num_slots = 3;
+    cfg->armor_size = IRMV_ARMOR_SMALL;
+    // config/camera_info.yaml:7,12
+    const double K[9] = {957.669211, 0, 345.943891, 0, 969.127115, 284.057302, 0, 0, 1};
+    const double D[5] = {-0.405274, 0.126058, -0.026939, -0.006503, 0.0};
+    memcpy(cfg->camera_matrix, K, sizeof K);
+    memcpy(cfg->dist_coeffs, D, sizeof D);
+}
+
+extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
+{
+    if (!cfg || !out) return fail(IRMV_ERR_ARG, "cfg/out is null");
+    if (cfg->struct_size != sizeof(irmv_engine_cfg)) return fail(IRMV_ERR_ARG, "irmv_engine_cfg size mismatch");
+    if (cfg->net_size < 64 || cfg->net_size % 32 != 0 || cfg->net_size > 2048) return fail(IRMV_ERR_ARG, "net_size must be a multiple of 32 in [64, 2048]");
+    if (cfg->src_width < 2 || cfg->src_height < 2 || cfg->src_width > 4096) return fail(IRMV_ERR_ARG, "src size out of range (width <= 4096)");
+    if (cfg->num_slots < 1 || cfg->num_slots > 64) return fail(IRMV_ERR_ARG, "num_slots must be 1..64");
+    if (cfg->max_det < 1 || cfg->max_det > IRMV_MAX_DET_CAP) return fail(IRMV_ERR_ARG, "max_det must be 1..256");
+    if (cfg->pre_nms_cap < 1 || cfg->pre_nms_cap > IRMV_CAND_CAP) return fail(IRMV_ERR_ARG, "pre_nms_cap must be 1..8192");
+    if (!(cfg->score_thr > 0.f && cfg->score_thr < 1.f)) return fail(IRMV_ERR_ARG, "score_thr must be in (0, 1)");
+    if (cfg->armor_size != IRMV_ARMOR_SMALL && cfg->armor_size != IRMV_ARMOR_LARGE) return fail(IRMV_ERR_ARG, "bad armor_size");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(IRMV_ERR_HIP, "no such HIP device");
+    std::unique_ptr<irmv_engine> e(new irmv_engine);
+    e->cfg = *cfg;
+    int rc = load_blob(e.get());
+    e->cfg.weights_path = nullptr;  // caller-owned, not retained
+    e->cfg.weights_blob = nullptr;
+    if (rc) return rc;
+    rc = build_engine(e.get());
+    if (rc) return rc;
+    *out = e.release();
+    return IRMV_OK;
+}
+
+extern "C" void irmv_engine_destroy(irmv_engine *e) { delete e; }
+extern "C" int irmv_engine_num_slots(const irmv_engine *e) { return e ? e->cfg.num_slots : 0; }
+extern "C" int irmv_engine_max_det(const irmv_engine *e) { return e ? e->cfg.max_det : 0; }
+extern "C" int irmv_engine_num_anchors(const irmv_engine *e) { return e ? e->A : 0; }
+extern "C" int irmv_engine_head_channels(const irmv_engine *e) { return e ? e->no : 0; }
+
+extern "C" uint8_t *irmv_engine_src_buffer(irmv_engine *e, int slot)
+{
+    if (!e || slot < 0 || slot >= e->cfg.num_slots) return nullptr;
+    return e->src_host + (size_t)slot * e->frame_bytes;
+}
+extern "C" void *irmv_engine_src_device_buffer(irmv_engine *e, int slot)
+{
+    if (!e || slot < 0 || slot >= e->cfg.num_slots) return nullptr;
+    return e->src_dev + (size_t)slot * e->frame_bytes;
+}
+
+// ---- step execution ------------------------------------------------------------
+struct EvRec { hipEvent_t a, b; };
+
+static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int count, ConvArgs &a)
+{
+    auto seg = [&](const SegRef &s) {
+        ConvSeg cs{nullptr, 0, 0, 0};
+        if (s.t < 0 || s.C == 0) return cs;
+        const Tensor &t = e->tensors[s.t];
+        cs.p = static_cast<const half_t *>(t.slot(first)) + s.coff;
+        cs.ld = t.C;
+        cs.C = s.C;
+        cs.shift = s.shift;
+        return cs;
+    };
+    a.s0 = seg(op.s0);
+    a.s1 = seg(op.s1);
+    a.Hin = op.Hin; a.Win = op.Win; a.Hout = op.Hout; a.Wout = op.Wout;
+    a.M = count * op.Hout * op.Wout;
+    a.Cin = op.cin;
+    a.w = op.w_packed;
+    a.bias = op.bias;
+    const Tensor &ot = e->tensors[op.out_t];
+    a.out = static_cast<char *>(ot.slot(first)) + (size_t)op.out_coff * ot.esize();
+    a.out_ld = ot.C;
+    a.res = nullptr;
+    a.res_ld = 0;
+    if (op.res_t >= 0) {
+        const Tensor &rt = e->tensors[op.res_t];
+        a.res = static_cast<const half_t *>(rt.slot(first)) + op.res_coff;
+        a.res_ld = rt.C;
+    }
+    a.cout_pad = op.cout_pad;
+    a.ksteps = op.ksteps;
+}
+
+static PostArgs post_args(const irmv_engine *e, int first)
+{
+    PostArgs p = e->post;
+    for (int i = 0; i < 3; i++) p.head[i] = static_cast<const float *>(e->tensors[e->head_t[i]].slot(first));
+    for (int i = 0; i < 3; i++) { p.lvl_hw[i] = e->lvl_hw[i]; p.lvl_base[i] = e->lvl_base[i]; }
+    p.boxes = e->boxes + (size_t)first * e->A * 4;
+    p.keys = e->keys + (size_t)first * kCandCap;
+    p.counts = e->counts + first;
+    p.dets = e->dets_dev + (size_t)first * e->cfg.max_det;
+    p.fout = e->fout_dev + first;
+    return p;
+}
+
+// Enqueue one step on the engine stream.  ev != nullptr: bracket every kernel with events.
+static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bool post_only, std::vector<EvRec> *ev)
+{
+    hipStream_t s = e->stream;
+    const int net = e->cfg.net_size;
+    if (!post_only && (flags & IRMV_SUBMIT_H2D))
+        HIP_TRY(hipMemcpyAsync(e->src_dev + (size_t)first * e->frame_bytes, e->src_host + (size_t)first * e->frame_bytes,
+                               e->frame_bytes * count, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->counts + first, 0, (size_t)count * 4, s));
+    const PostArgs pa = post_args(e, first);
+    for (const Op &op : e->ops) {
+        if (post_only && op.kind != OP_DECODE && op.kind != OP_NMS) continue;
+        EvRec r{};
+        if (ev) {
+            HIP_TRY(hipEventCreate(&r.a));
+            HIP_TRY(hipEventCreate(&r.b));
+            HIP_TRY(hipEventRecord(r.a, s));
+        }
+        switch (op.kind) {
+        case OP_PRE: {
+            PreArgs a;
+            a.src = e->src_dev + (size_t)first * e->frame_bytes;
+            a.dst = static_cast<half_t *>(e->tensors[e->tensor_idx.at("input")].slot(first));
+            a.tx = e->tap_x; a.ty = e->tap_y;
+            a.sw = e->cfg.src_width; a.sh = e->cfg.src_height; a.net = net; a.swap_rb = e->cfg.swap_rb;
+            a.src_slot_bytes = e->frame_bytes;
+            launch_preprocess(a, count, s);
+            break;
+        }
+        case OP_CONV0: {
+            Conv0Args a;
+            a.x = static_cast<const half_t *>(e->tensors[e->tensor_idx.at("input")].slot(first));
+            a.y = static_cast<half_t *>(e->tensors[e->tensor_idx.at("0")].slot(first));
+            a.w = e->conv0_w; a.b = e->conv0_b; a.net = net; a.batch = count;
+            launch_conv0(a, s);
+            break;
+        }
+        case OP_CONV: {
+            ConvArgs a;
+            fill_conv_args(e, op, first, count, a);
+            if (!launch_conv(op.cfg, a, s)) return fail(IRMV_ERR_ARG, std::string("no conv kernel for ") + op.kname + " (" + op.layer + ")");
+            break;
+        }
+        case OP_POOL: {
+            const Tensor &t = e->tensors[e->tensor_idx.at("9.cat")];
+            launch_sppf_pool(static_cast<half_t *>(t.slot(first)), count, t.H, t.W, t.C / 4, s);
+            break;
+        }
+        case OP_DECODE: launch_decode(pa, count, s); break;
+        case OP_NMS: launch_nms_pnp(pa, count, s); break;
+        }
+        HIP_TRY(hipGetLastError());
+        if (ev) {
+            HIP_TRY(hipEventRecord(r.b, s));
+            ev->push_back(r);
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(e->dets_host + (size_t)first * e->cfg.max_det, e->dets_dev + (size_t)first * e->cfg.max_det,
+                           (size_t)count * e->cfg.max_det * sizeof(DevDet), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(e->fout_host + first, e->fout_dev + first, (size_t)count * sizeof(DevFrameOut),
+                           hipMemcpyDeviceToHost, s));
+    return IRMV_OK;
+}
+
+static int check_range(const irmv_engine *e, int first, int count)
+{
+    if (!e) return fail(IRMV_ERR_ARG, "engine is null");
+    if (first < 0 || count < 1 || first + count > e->cfg.num_slots) return fail(IRMV_ERR_ARG, "slot range out of bounds");
+    return IRMV_OK;
+}
+
+static int get_graph(irmv_engine *e, int first, int count, uint32_t flags, bool post_only, hipGraphExec_t *out)
+{
+    const GraphKey key{first, count, flags | (post_only ? 0x80000000u : 0u)};
+    auto it = e->graphs.find(key);
+    if (it != e->graphs.end()) { *out = it->second; return IRMV_OK; }
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_step(e, first, count, flags, post_only, nullptr);
+    hipError_t ce = hipStreamEndCapture(e->stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (ce != hipSuccess) return fail(IRMV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    hipGraphExec_t ge = nullptr;
+    HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    e->graphs[key] = ge;
+    *out = ge;
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_submit(irmv_engine *e, int first, int count, uint32_t flags)
+{
+    TRY(check_range(e, first, count));
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipGraphExec_t ge;
+    TRY(get_graph(e, first, count, flags & IRMV_SUBMIT_H2D, false, &ge));
+    HIP_TRY(hipGraphLaunch(ge, e->stream));
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_run_post(irmv_engine *e, int first, int count)
+{
+    TRY(check_range(e, first, count));
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipGraphExec_t ge;
+    TRY(get_graph(e, first, count, 0, true, &ge));
+    HIP_TRY(hipGraphLaunch(ge, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_wait(irmv_engine *e)
+{
+    if (!e) return fail(IRMV_ERR_ARG, "engine is null");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_results(irmv_engine *e, int slot, irmv_det *out, int cap, int *n)
+{
+    TRY(check_range(e, slot, 1));
+    if (!n || (cap > 0 && !out)) return fail(IRMV_ERR_ARG, "out/n is null");
+    const DevFrameOut &fo = e->fout_host[slot];
+    const int k = std::min(fo.num_dets, cap);
+    const DevDet *d = e->dets_host + (size_t)slot * e->cfg.max_det;
+    for (int i = 0; i < k; i++) {
+        irmv_det &o = out[i];
+        memcpy(o.xyxy, d[i].xyxy, 16);
+        o.score = d[i].score;
+        // magic_enum::enum_cast<ArmorClass>(label).value_or(UNKNOWN), src/yolo_engine.cpp:216
+        o.class_id = (d[i].cls >= 0 && d[i].cls < IRMV_NUM_CLASSES) ? d[i].cls : IRMV_NUM_CLASSES;
+        o.anchor = d[i].anchor;
+        o.pnp_ok = d[i].pnp_ok;
+        memcpy(o.kpts, d[i].kpts, 32);
+        memcpy(o.rvec, d[i].rvec, 24);
+        memcpy(o.tvec, d[i].tvec, 24);
+        memcpy(o.quat, d[i].quat, 32);
+    }
+    *n = k;
+    if (fo.overflow) return fail(IRMV_ERR_OVERFLOW, "more than IRMV_CAND_CAP candidates above score_thr; raise score_thr");
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_detect(irmv_engine *e, int slot, irmv_det *out, int cap, int *n)
+{
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    TRY(irmv_engine_submit(e, slot, 1, IRMV_SUBMIT_H2D));
+    TRY(irmv_engine_wait(e));
+    const int rc = irmv_engine_results(e, slot, out, cap, n);
+    e->last_detect_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    return rc;
+}
+
+extern "C" double irmv_engine_last_detect_ms(const irmv_engine *e) { return e ? e->last_detect_ms : 0.0; }
+
+extern "C" int irmv_engine_rotated_image(irmv_engine *e, int slot, uint8_t *dst)
+{
+    TRY(check_range(e, slot, 1));
+    if (!dst) return fail(IRMV_ERR_ARG, "dst is null");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipMemcpyAsync(e->src_dev + (size_t)slot * e->frame_bytes, e->src_host + (size_t)slot * e->frame_bytes,
+                           e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+    launch_rotate180(e->src_dev + (size_t)slot * e->frame_bytes, e->rot_dev, e->cfg.src_width, e->cfg.src_height, e->stream);
+    HIP_TRY(hipMemcpyAsync(dst, e->rot_dev, e->frame_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return IRMV_OK;
+}
+
+// ---- read-backs --------------------------------------------------------------------
+static int read_tensor_f32(irmv_engine *e, const Tensor &t, int slot, std::vector<float> &out)
+{
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    out.resize(t.slot_elems);
+    if (t.f32) {
+        HIP_TRY(hipMemcpy(out.data(), t.slot(slot), t.slot_elems * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint16_t> h(t.slot_elems);
+        HIP_TRY(hipMemcpy(h.data(), t.slot(slot), t.slot_elems * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < t.slot_elems; i++) out[i] = half_bits_to_float(h[i]);
+    }
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_read_input(irmv_engine *e, int slot, float *chw)
+{
+    TRY(check_range(e, slot, 1));
+    std::vector<float> v;
+    TRY(read_tensor_f32(e, e->tensors[e->tensor_idx.at("input")], slot, v));
+    const size_t n = (size_t)e->cfg.net_size * e->cfg.net_size;
+    for (size_t p = 0; p < n; p++)
+        for (int c = 0; c < 3; c++) chw[c * n + p] = v[p * 4 + c];
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_read_head(irmv_engine *e, int slot, float *head)
+{
+    TRY(check_range(e, slot, 1));
+    for (int l = 0; l < 3; l++) {
+        std::vector<float> v;
+        TRY(read_tensor_f32(e, e->tensors[e->head_t[l]], slot, v));
+        for (int p = 0; p < e->lvl_hw[l]; p++) {
+            float *o = head + (size_t)(e->lvl_base[l] + p) * e->no;
+            const float *r = v.data() + (size_t)p * kHeadRec;
+            memcpy(o, r, 64 * 4);
+            memcpy(o + 64, r + kClsOff, (size_t)e->nc * 4);
+            if (e->nk) memcpy(o + 64 + e->nc, r + kKptOff, (size_t)e->nk * 4);
+        }
+    }
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_write_head(irmv_engine *e, int slot, const float *head)
+{
+    TRY(check_range(e, slot, 1));
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int l = 0; l < 3; l++) {
+        std::vector<float> v((size_t)e->lvl_hw[l] * kHeadRec, 0.f);
+        for (int p = 0; p < e->lvl_hw[l]; p++) {
+            const float *o = head + (size_t)(e->lvl_base[l] + p) * e->no;
+            float *r = v.data() + (size_t)p * kHeadRec;
+            memcpy(r, o, 64 * 4);
+            memcpy(r + kClsOff, o + 64, (size_t)e->nc * 4);
+            if (e->nk) memcpy(r + kKptOff, o + 64 + e->nc, (size_t)e->nk * 4);
+        }
+        HIP_TRY(hipMemcpy(e->tensors[e->head_t[l]].slot(slot), v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    }
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_read_tap(irmv_engine *e, int slot, const char *name, float *nhwc, int shape[3])
+{
+    TRY(check_range(e, slot, 1));
+    if (!name || !shape) return fail(IRMV_ERR_ARG, "name/shape is null");
+    auto it = e->tensor_idx.find(name);
+    if (it == e->tensor_idx.end()) return fail(IRMV_ERR_ARG, std::string("no tensor named ") + name);
+    const Tensor &t = e->tensors[it->second];
+    shape[0] = t.H; shape[1] = t.W; shape[2] = t.C;
+    if (!nhwc) return IRMV_OK;
+    std::vector<float> v;
+    TRY(read_tensor_f32(e, t, slot, v));
+    memcpy(nhwc, v.data(), v.size() * 4);
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_read_raw(irmv_engine *e, int slot, irmv_raw_dets *out)
+{
+    TRY(check_range(e, slot, 1));
+    if (!out) return fail(IRMV_ERR_ARG, "out is null");
+    const DevFrameOut &fo = e->fout_host[slot];
+    const DevDet *d = e->dets_host + (size_t)slot * e->cfg.max_det;
+    out->num_dets = fo.num_dets;
+    out->n_candidates = fo.n_candidates;
+    for (int i = 0; i < e->cfg.max_det; i++) {
+        if (out->det_boxes) memcpy(out->det_boxes + 4 * i, d[i].box_net, 16);
+        if (out->det_scores) out->det_scores[i] = d[i].score;
+        if (out->det_classes) out->det_classes[i] = d[i].cls;
+        if (out->det_anchors) out->det_anchors[i] = d[i].anchor;
+        if (out->det_kpts) memcpy(out->det_kpts + 8 * i, d[i].kpts_net, 32);
+    }
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_kernel_stat *stats, int cap, int *n)
+{
+    TRY(check_range(e, first, count));
+    if (!n) return fail(IRMV_ERR_ARG, "n is null");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    std::vector<EvRec> ev;
+    TRY(enqueue_step(e, first, count, 0, false, &ev));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int k = 0;
+    for (size_t i = 0; i < ev.size(); i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[i].a, ev[i].b));
+        (void)hipEventDestroy(ev[i].a);
+        (void)hipEventDestroy(ev[i].b);
+        if (k < cap && stats) {
+            const Op &op = e->ops[i];
+            irmv_kernel_stat &st = stats[k];
+            memset(&st, 0, sizeof st);
+            snprintf(st.name, sizeof st.name, "%s", op.kname);
+            snprintf(st.layer, sizeof st.layer, "%s", op.layer.c_str());
+            st.flops = op.flops * count;
+            st.bytes = op.bytes * count;
+            st.ms = ms;
+        }
+        k++;
+    }
+    *n = k;
+    return IRMV_OK;
+}
+
+// ---- PnPSolver -------------------------------------------------------------------------
+struct irmv_pnp {
+    int device = 0;
+    PnpConst c{};
+    hipStream_t stream = nullptr;
+    float *pts = nullptr;
+    double *rvec = nullptr, *tvec = nullptr;
+    int32_t *ok = nullptr;
+    int cap = 0;
+};
+
+static void pnp_free(irmv_pnp *p)
+{
+    if (p->pts) (void)hipFree(p->pts);
+    if (p->rvec) (void)hipFree(p->rvec);
+    if (p->tvec) (void)hipFree(p->tvec);
+    if (p->ok) (void)hipFree(p->ok);
+    p->pts = nullptr; p->rvec = p->tvec = nullptr; p->ok = nullptr; p->cap = 0;
+}
+
+extern "C" int irmv_pnp_create(int device, const double K[9], const double D[5], irmv_pnp **out)
+{
+    if (!K || !D || !out) return fail(IRMV_ERR_ARG, "null argument");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(IRMV_ERR_HIP, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<irmv_pnp> p(new irmv_pnp);
+    p->device = device;
+    p->c.fx = K[0]; p->c.fy = K[4]; p->c.cx = K[2]; p->c.cy = K[5];
+    p->c.k1 = D[0]; p->c.k2 = D[1]; p->c.p1 = D[2]; p->c.p2 = D[3]; p->c.k3 = D[4];
+    p->c.hy[0] = 135.0 / 2.0 / 1000.0; p->c.hy[1] = 225.0 / 2.0 / 1000.0;
+    p->c.hz[0] = p->c.hz[1] = 55.0 / 2.0 / 1000.0;
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    *out = p.release();
+    return IRMV_OK;
+}
+
+extern "C" void irmv_pnp_destroy(irmv_pnp *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    pnp_free(p);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+extern "C" int irmv_pnp_solve(irmv_pnp *p, const float *img_pts, int n, int armor_size, double *rvec, double *tvec, int32_t *ok)
+{
+    if (!p || !img_pts || !rvec || !tvec || !ok || n < 0) return fail(IRMV_ERR_ARG, "null argument");
+    if (armor_size != IRMV_ARMOR_SMALL && armor_size != IRMV_ARMOR_LARGE) return fail(IRMV_ERR_ARG, "bad armor_size");
+    if (n == 0) return IRMV_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    if (n > p->cap) {
+        pnp_free(p);
+        const int cap = std::max(n, 64);
+        HIP_TRY(hipMalloc((void **)&p->pts, (size_t)cap * 32));
+        HIP_TRY(hipMalloc((void **)&p->rvec, (size_t)cap * 24));
+        HIP_TRY(hipMalloc((void **)&p->tvec, (size_t)cap * 24));
+        HIP_TRY(hipMalloc((void **)&p->ok, (size_t)cap * 4));
+        p->cap = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(p->pts, img_pts, (size_t)n * 32, hipMemcpyHostToDevice, p->stream));
+    launch_pnp_only(p->c, p->pts, n, armor_size, p->rvec, p->tvec, p->ok, p->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rvec, p->rvec, (size_t)n * 24, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(tvec, p->tvec, (size_t)n * 24, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(ok, p->ok, (size_t)n * 4, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return IRMV_OK;
+}

@@ -1,0 +1,117 @@
+// Shared declarations of the gfx950 kernels and their host launchers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace irmv {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHeadRec = 96;   // fp32 per anchor: box 64 | cls 16 (nc<=16) | kpt 16 (nk<=16)
+constexpr int kClsOff = 64;
+constexpr int kKptOff = 80;
+constexpr int kCandCap = 8192; // == IRMV_CAND_CAP
+constexpr int kMaxDetCap = 256;
+
+// ---- preprocess ------------------------------------------------------------
+// One bilinear tap table entry per destination coordinate (built on the host
+// with the integer arithmetic of the oracle's axis_tap; rotate180 already folded
+// into i0/i1).  i0 < 0 marks a letterbox pad coordinate.
+struct AxisTap { int32_t i0, i1, w1, pad; };
+
+struct PreArgs {
+    const uint8_t *src;   // [B][sh][sw][3]
+    half_t *dst;          // [B][net][net][4]
+    const AxisTap *tx, *ty;
+    int sw, sh, net, swap_rb;
+    size_t src_slot_bytes;
+};
+void launch_preprocess(const PreArgs &a, int batch, hipStream_t s);
+void launch_rotate180(const uint8_t *src, uint8_t *dst, int sw, int sh, hipStream_t s);
+
+// model.0.conv: 3x3 s2, 3(+1 pad) -> 16, SiLU, VALU kernel
+struct Conv0Args {
+    const half_t *x;      // [B][net][net][4]
+    half_t *y;            // [B][net/2][net/2][16]
+    const float *w;       // [27][16] (tap, cin, cout)
+    const float *b;       // [16]
+    int net, batch;
+};
+void launch_conv0(const Conv0Args &a, hipStream_t s);
+
+// ---- implicit-GEMM conv on MFMA ----------------------------------------------
+struct ConvSeg {
+    const half_t *p;  // base pointer, already offset to the segment's first channel
+    int ld;           // channel stride of a pixel, in elements
+    int C;            // channels taken from this segment (multiple of 8); 0 = unused
+    int shift;        // 1 = the segment is stored at half resolution (nearest 2x upsample folded in)
+};
+
+struct ConvArgs {
+    ConvSeg s0, s1;
+    int Hin, Win;       // input size at the conv's own resolution
+    int Hout, Wout;
+    int M;              // batch * Hout * Wout
+    int Cin;            // s0.C + s1.C
+    const half_t *w;    // packed MFMA A fragments [ntile][kstep][64 lanes][8]
+    const float *bias;  // [cout_pad]
+    void *out;          // half_t* or float*, already offset to the first output channel
+    int out_ld;
+    const half_t *res;  // optional residual (same pixel indexing as out), nullable
+    int res_ld;
+    int cout_pad;       // multiple of 16
+    int ksteps;
+};
+
+struct ConvCfg { int ks, stride, mt, nt; bool cin16; int act; bool out_f32; };
+// returns false if no instantiation exists for cfg
+bool launch_conv(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
+const char *conv_cfg_name(const ConvCfg &cfg, char *buf, int n);
+
+// SPPF pooling chain: slice 0 (C ch) of [B][H][W][4C] -> slices 1..3 (5x5, 9x9, 13x13 max)
+void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s);
+
+// ---- post-processing -----------------------------------------------------------
+struct DevDet {           // device/pinned result record
+    float box_net[4];     // xyxy, net-input pixels (EfficientNMS det_boxes)
+    float xyxy[4];        // source-frame pixels (parse_output)
+    float score;
+    int32_t cls, anchor, pnp_ok;
+    float kpts_net[8];
+    float kpts[8];
+    double rvec[3], tvec[3], quat[4];
+};
+struct DevFrameOut { int32_t num_dets, n_candidates, overflow, pad; };
+
+struct PnpConst {
+    double fx, fy, cx, cy, k1, k2, p1, p2, k3;
+    double hy[2], hz[2];   // half extents of the small / large armor (metres)
+};
+
+struct PostArgs {
+    const float *head[3];     // per Detect level: [B][H*W][kHeadRec]
+    int lvl_hw[3], lvl_base[3];
+    float *boxes;             // [B][A][4]
+    unsigned long long *keys; // [B][kCandCap]
+    int *counts;              // [B]
+    DevDet *dets;             // [B][max_det]
+    DevFrameOut *fout;        // [B]
+    int net, A, nc, nk;
+    float logit_thr, iou_thr;
+    int max_det, pre_nms_cap;
+    // parse_output mapping net -> source frame: x_src = (x - off_x) * scale_x
+    float scale_x, scale_y, off_x, off_y;
+    int armor_size;
+    PnpConst pnp;
+};
+void launch_decode(const PostArgs &a, int batch, hipStream_t s);
+void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s);
+void launch_pnp_only(const PnpConst &c, const float *pts, int n, int armor_size, double *rvec, double *tvec,
+                     int32_t *ok, hipStream_t s);
+
+}  // namespace irmv

@@ -1,0 +1,501 @@
+// Detection post-processing on the GPU: DFL box decode + score filter, score
+// sort, class-aware greedy NMS, keypoint decode, parse_output scaling and planar
+// (IPPE) PnP -- everything the reference does after the conv body:
+//   EfficientNMS_TRT plugin   (bound at src/yolo_engine.cpp:53-57,82-85)
+//   YoloEngine::parse_output  (src/yolo_engine.cpp:202-220)
+//   PnPSolver::solvePnP       (src/pnp_solver.cpp:36-52, cv::SOLVEPNP_IPPE)
+//   Rodrigues -> quaternion   (src/irm_detector.cpp:218-226)
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off: the fp32 decode / IoU
+// expressions are evaluated exactly as written (fmaf only where spelled out), so
+// candidate sets, sort order and NMS survivors are bit-reproducible against the
+// CPU oracle on identical head tensors.
+//
+// Latency-bound integer/compare work: one lane per anchor for the decode, one
+// workgroup per frame for sort + NMS, the IoU test of a 64-candidate block
+// against the kept set and against itself done wave-wide with ballots.
+#include "irmv_common.hpp"
+
+namespace irmv {
+
+// exp(x) as a fixed sequence of fp32 operations (same sequence in oracle/orc_post.c)
+__device__ __forceinline__ float irmv_expf(float x)
+{
+    x = x < -87.0f ? -87.0f : x;
+    x = x > 88.0f ? 88.0f : x;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.0f / 720.0f;
+    p = fmaf(p, r, 1.0f / 120.0f);
+    p = fmaf(p, r, 1.0f / 24.0f);
+    p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    return __int_as_float(__float_as_int(p) + ((int)n << 23));
+}
+
+__device__ __forceinline__ uint32_t orderable(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unorderable(uint32_t u)
+{
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ void anchor_geom(int a, int net, int &ix, int &iy, int &stride, int &lvl, int &rin)
+{
+    int base = 0;
+    ix = iy = 0;
+    stride = 0;
+    lvl = 0;
+    rin = 0;
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        const int s = 8 << l, w = net / s, cnt = w * w;
+        if (stride == 0 && a < base + cnt) {
+            const int r = a - base;
+            iy = r / w;
+            ix = r - iy * w;
+            stride = s;
+            lvl = l;
+            rin = r;
+        }
+        base += cnt;
+    }
+}
+
+__device__ __forceinline__ const float *head_rec(const PostArgs &a, int b, int lvl, int rin)
+{
+    const float *h = lvl == 0 ? a.head[0] : (lvl == 1 ? a.head[1] : a.head[2]);
+    const int hw = lvl == 0 ? a.lvl_hw[0] : (lvl == 1 ? a.lvl_hw[1] : a.lvl_hw[2]);
+    return h + ((size_t)b * hw + rin) * kHeadRec;
+}
+
+__device__ __forceinline__ float dfl_side(const float *l)
+{
+    float m = l[0];
+#pragma unroll
+    for (int j = 1; j < 16; j++) m = l[j] > m ? l[j] : m;
+    float se = 0.0f, sj = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float e = irmv_expf(l[j] - m);
+        se = se + e;
+        sj = sj + e * (float)j;
+    }
+    return sj / se;
+}
+
+// One lane per (frame, anchor): box -> boxes[], passing (anchor, class) pairs -> keys[]
+__global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * a.A) return;
+    const int b = t / a.A, an = t - b * a.A;
+    int ix, iy, s, lvl, rin;
+    anchor_geom(an, a.net, ix, iy, s, lvl, rin);
+    const float *rec = head_rec(a, b, lvl, rin);
+    float l[64];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(rec)[i];
+        l[4 * i] = v[0]; l[4 * i + 1] = v[1]; l[4 * i + 2] = v[2]; l[4 * i + 3] = v[3];
+    }
+    const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)s;
+    const float dl = dfl_side(l), dt = dfl_side(l + 16), dr = dfl_side(l + 32), db = dfl_side(l + 48);
+    f32x4 box;
+    box[0] = (ax - dl) * sf;
+    box[1] = (ay - dt) * sf;
+    box[2] = (ax + dr) * sf;
+    box[3] = (ay + db) * sf;
+    reinterpret_cast<f32x4 *>(a.boxes)[t] = box;
+    for (int c = 0; c < a.nc; c++) {
+        const float logit = rec[kClsOff + c];
+        if (logit > a.logit_thr) {
+            const int idx = atomicAdd(&a.counts[b], 1);
+            if (idx < kCandCap)
+                a.keys[(size_t)b * kCandCap + idx] =
+                    ((unsigned long long)orderable(logit) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(an * a.nc + c));
+        }
+    }
+}
+
+void launch_decode(const PostArgs &a, int batch, hipStream_t s)
+{
+    const int total = batch * a.A;
+    hipLaunchKernelGGL(decode_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a, batch);
+}
+
+__device__ __forceinline__ float iou_xyxy(const f32x4 a, const f32x4 b)
+{
+    const float ix1 = a[0] > b[0] ? a[0] : b[0];
+    const float iy1 = a[1] > b[1] ? a[1] : b[1];
+    const float ix2 = a[2] < b[2] ? a[2] : b[2];
+    const float iy2 = a[3] < b[3] ? a[3] : b[3];
+    float iw = ix2 - ix1, ih = iy2 - iy1;
+    iw = iw > 0.0f ? iw : 0.0f;
+    ih = ih > 0.0f ? ih : 0.0f;
+    const float inter = iw * ih;
+    const float aa = (a[2] - a[0]) * (a[3] - a[1]);
+    const float ab = (b[2] - b[0]) * (b[3] - b[1]);
+    const float uni = (aa + ab) - inter;
+    return inter / uni;
+}
+
+// ---------------------------------------------------------------------------
+// Planar PnP (IPPE, Collins & Bartoli 2014) for the armor rectangle, fp64, one
+// lane per armor.  The object points (src/pnp_solver.cpp:18-33) are
+// (0, +-hy, +-hz): already centred, plane normal = model x.  Canonical frame:
+// Xc = y_model, Yc = z_model, Zc = x_model (a proper rotation).  The homography
+// canonical plane -> normalised image is the closed-form rectangle->quad map.
+// ---------------------------------------------------------------------------
+struct Pose { double R[9]; double t[3]; double err; };
+
+__device__ void undistort4(const PnpConst &c, const float *pts, double *nxy)
+{
+    for (int i = 0; i < 4; i++) {
+        const double x0 = ((double)pts[2 * i] - c.cx) / c.fx, y0 = ((double)pts[2 * i + 1] - c.cy) / c.fy;
+        double x = x0, y = y0;
+        for (int it = 0; it < 5; it++) {
+            const double r2 = x * x + y * y;
+            const double icd = 1.0 / (1.0 + ((c.k3 * r2 + c.k2) * r2 + c.k1) * r2);
+            const double dx = 2.0 * c.p1 * x * y + c.p2 * (r2 + 2.0 * x * x);
+            const double dy = c.p1 * (r2 + 2.0 * y * y) + 2.0 * c.p2 * x * y;
+            x = (x0 - dx) * icd;
+            y = (y0 - dy) * icd;
+        }
+        nxy[2 * i] = x;
+        nxy[2 * i + 1] = y;
+    }
+}
+
+__device__ bool ippe_translation(const double *cx, const double *cy, const double *nxy, const double *R, double *t)
+{
+    double a02 = 0, a12 = 0, a22 = 0, b0 = 0, b1 = 0, b2 = 0;
+    for (int i = 0; i < 4; i++) {
+        const double X = cx[i], Y = cy[i], x = nxy[2 * i], y = nxy[2 * i + 1];
+        const double rx = R[0] * X + R[1] * Y, ry = R[3] * X + R[4] * Y, rz = R[6] * X + R[7] * Y;
+        const double e1 = x * rz - rx, e2 = y * rz - ry;
+        a02 -= x; a12 -= y; a22 += x * x + y * y;
+        b0 += e1; b1 += e2; b2 += -x * e1 - y * e2;
+    }
+    // A = [[4,0,a02],[0,4,a12],[a02,a12,a22]]
+    const double det = 4.0 * (4.0 * a22 - a12 * a12) - a02 * (4.0 * a02);
+    if (!(fabs(det) > 1e-300)) return false;
+    const double i00 = 4.0 * a22 - a12 * a12, i01 = a02 * a12, i02 = -4.0 * a02;
+    const double i11 = 4.0 * a22 - a02 * a02, i12 = -4.0 * a12, i22 = 16.0;
+    t[0] = (i00 * b0 + i01 * b1 + i02 * b2) / det;
+    t[1] = (i01 * b0 + i11 * b1 + i12 * b2) / det;
+    t[2] = (i02 * b0 + i12 * b1 + i22 * b2) / det;
+    return true;
+}
+
+__device__ void rot_to_rvec(const double *R, double *r)
+{
+    double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    const double ax = R[7] - R[5], ay = R[2] - R[6], az = R[3] - R[1];
+    const double s = 0.5 * sqrt(ax * ax + ay * ay + az * az);
+    const double th = atan2(s, c);
+    if (s > 1e-9) {
+        const double k = th / (2.0 * s);
+        r[0] = ax * k; r[1] = ay * k; r[2] = az * k;
+    } else if (c > 0.0) {
+        r[0] = r[1] = r[2] = 0.0;
+    } else {
+        double xx = sqrt(fmax((R[0] + 1.0) * 0.5, 0.0));
+        double yy = sqrt(fmax((R[4] + 1.0) * 0.5, 0.0));
+        double zz = sqrt(fmax((R[8] + 1.0) * 0.5, 0.0));
+        if (R[1] + R[3] < 0.0) yy = -yy;
+        if (R[2] + R[6] < 0.0) zz = -zz;
+        if (xx == 0.0 && R[5] + R[7] < 0.0) zz = -zz;
+        const double nn = sqrt(xx * xx + yy * yy + zz * zz);
+        r[0] = th * xx / nn; r[1] = th * yy / nn; r[2] = th * zz / nn;
+    }
+}
+
+__device__ void rot_to_quat(const double *R, double *q)
+{
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0.0) {
+        double s = sqrt(tr + 1.0);
+        q[3] = s * 0.5;
+        s = 0.5 / s;
+        q[0] = (R[7] - R[5]) * s; q[1] = (R[2] - R[6]) * s; q[2] = (R[3] - R[1]) * s;
+    } else if (R[0] >= R[4] && R[0] >= R[8]) {
+        double s = sqrt(R[0] - R[4] - R[8] + 1.0);
+        q[0] = s * 0.5; s = 0.5 / s;
+        q[3] = (R[7] - R[5]) * s; q[1] = (R[3] + R[1]) * s; q[2] = (R[6] + R[2]) * s;
+    } else if (R[4] >= R[8]) {
+        double s = sqrt(R[4] - R[8] - R[0] + 1.0);
+        q[1] = s * 0.5; s = 0.5 / s;
+        q[3] = (R[2] - R[6]) * s; q[2] = (R[7] + R[5]) * s; q[0] = (R[1] + R[3]) * s;
+    } else {
+        double s = sqrt(R[8] - R[0] - R[4] + 1.0);
+        q[2] = s * 0.5; s = 0.5 / s;
+        q[3] = (R[3] - R[1]) * s; q[0] = (R[2] + R[6]) * s; q[1] = (R[5] + R[7]) * s;
+    }
+}
+
+// pts: LB, LT, RT, RB in source-frame pixels (src/pnp_solver.cpp:41-44)
+__device__ bool solve_pnp_ippe(const PnpConst &c, const float *pts, int armor_size, double *rvec, double *tvec, double *quat)
+{
+    const double hy = c.hy[armor_size], hz = c.hz[armor_size];
+    double nxy[8];
+    undistort4(c, pts, nxy);
+    // canonical (Xc, Yc) of LB, LT, RT, RB = (y_model, z_model)
+    const double cX[4] = {hy, hy, -hy, -hy}, cY[4] = {-hz, hz, hz, -hz};
+    // unit square (u, v) = ((hy - Xc) / 2hy, (Yc + hz) / 2hz): (0,0)=LB (1,0)=RB (1,1)=RT (0,1)=LT
+    const double x0 = nxy[0], y0 = nxy[1], x1 = nxy[6], y1 = nxy[7], x2 = nxy[4], y2 = nxy[5], x3 = nxy[2], y3 = nxy[3];
+    const double dx1 = x1 - x2, dx2 = x3 - x2, sx = x0 - x1 + x2 - x3;
+    const double dy1 = y1 - y2, dy2 = y3 - y2, sy = y0 - y1 + y2 - y3;
+    const double den = dx1 * dy2 - dy1 * dx2;
+    if (!(fabs(den) > 1e-300)) return false;
+    const double gg = (sx * dy2 - dx2 * sy) / den, hh = (dx1 * sy - sx * dy1) / den;
+    const double sa = x1 - x0 + gg * x1, sb = x3 - x0 + hh * x3, sc = x0;
+    const double sd = y1 - y0 + gg * y1, se = y3 - y0 + hh * y3, sf = y0;
+    // H = Hs * [[-1/2hy, 0, 1/2], [0, 1/2hz, 1/2], [0, 0, 1]]
+    const double iu = -0.5 / hy, iv = 0.5 / hz;
+    double H[9] = {sa * iu, sb * iv, 0.5 * sa + 0.5 * sb + sc,
+                   sd * iu, se * iv, 0.5 * sd + 0.5 * se + sf,
+                   gg * iu, hh * iv, 0.5 * gg + 0.5 * hh + 1.0};
+    if (!(fabs(H[8]) > 1e-300)) return false;
+    const double ih = 1.0 / H[8];
+    for (int i = 0; i < 9; i++) H[i] *= ih;
+    const double p = H[2], q = H[5];
+    const double j00 = H[0] - H[6] * p, j01 = H[1] - H[7] * p, j10 = H[3] - H[6] * q, j11 = H[4] - H[7] * q;
+
+    // rotation taking the optical axis onto the ray through the plane origin
+    double rv[9];
+    const double s = sqrt(p * p + q * q + 1.0), t = sqrt(p * p + q * q);
+    const double costh = 1.0 / s, sinth = sqrt(1.0 - 1.0 / (s * s));
+    if (t < 1e-300) {
+        rv[0] = 1; rv[1] = 0; rv[2] = 0; rv[3] = 0; rv[4] = 1; rv[5] = 0; rv[6] = 0; rv[7] = 0; rv[8] = 1;
+    } else {
+        const double k0 = p / t, k1 = q / t;
+        rv[0] = (costh - 1.0) * k0 * k0 + 1.0; rv[1] = k0 * k1 * (costh - 1.0); rv[2] = k0 * sinth;
+        rv[3] = rv[1]; rv[4] = (costh - 1.0) * k1 * k1 + 1.0; rv[5] = k1 * sinth;
+        rv[6] = -k0 * sinth; rv[7] = -k1 * sinth; rv[8] = (costh - 1.0) * (k0 * k0 + k1 * k1) + 1.0;
+    }
+    const double b00 = rv[0] - p * rv[6], b01 = rv[1] - p * rv[7], b10 = rv[3] - q * rv[6], b11 = rv[4] - q * rv[7];
+    const double bdet = b00 * b11 - b01 * b10;
+    if (!(fabs(bdet) > 1e-300)) return false;
+    const double dti = 1.0 / bdet;
+    const double a00 = dti * (b11 * j00 - b01 * j10), a01 = dti * (b11 * j01 - b01 * j11);
+    const double a10 = dti * (-b10 * j00 + b00 * j10), a11 = dti * (-b10 * j01 + b00 * j11);
+    const double ata00 = a00 * a00 + a01 * a01, ata01 = a00 * a10 + a01 * a11, ata11 = a10 * a10 + a11 * a11;
+    const double g2 = 0.5 * (ata00 + ata11 + sqrt((ata00 - ata11) * (ata00 - ata11) + 4.0 * ata01 * ata01));
+    if (!(g2 > 0.0)) return false;
+    const double gam = sqrt(g2);
+    const double r00 = a00 / gam, r01 = a01 / gam, r10 = a10 / gam, r11 = a11 / gam;
+    const double bb0 = sqrt(fmax(1.0 - r00 * r00 - r10 * r10, 0.0));
+    double bb1 = sqrt(fmax(1.0 - r01 * r01 - r11 * r11, 0.0));
+    if (-r00 * r01 - r10 * r11 < 0.0) bb1 = -bb1;
+
+    Pose best, other;
+    for (int sol = 0; sol < 2; sol++) {
+        const double c0 = sol ? -bb0 : bb0, c1 = sol ? -bb1 : bb1;
+        const double m[9] = {r00, r01, r10 * c1 - c0 * r11, r10, r11, c0 * r01 - r00 * c1, c0, c1, r00 * r11 - r01 * r10};
+        Pose ps;
+        double Rc[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Rc[i * 3 + j] = rv[i * 3] * m[j] + rv[i * 3 + 1] * m[3 + j] + rv[i * 3 + 2] * m[6 + j];
+        if (!ippe_translation(cX, cY, nxy, Rc, ps.t)) return false;
+        double e = 0.0;
+        for (int i = 0; i < 4; i++) {
+            const double X = Rc[0] * cX[i] + Rc[1] * cY[i] + ps.t[0];
+            const double Y = Rc[3] * cX[i] + Rc[4] * cY[i] + ps.t[1];
+            const double Z = Rc[6] * cX[i] + Rc[7] * cY[i] + ps.t[2];
+            const double ex = X / Z - nxy[2 * i], ey = Y / Z - nxy[2 * i + 1];
+            e += ex * ex + ey * ey;
+        }
+        ps.err = sqrt(e / 8.0);
+        // model = canonical^T: columns (x_m, y_m, z_m) = (Zc, Xc, Yc)
+        for (int i = 0; i < 3; i++) {
+            ps.R[i * 3 + 0] = Rc[i * 3 + 2];
+            ps.R[i * 3 + 1] = Rc[i * 3 + 0];
+            ps.R[i * 3 + 2] = Rc[i * 3 + 1];
+        }
+        if (sol == 0) best = ps; else other = ps;
+    }
+    if (!(best.err <= other.err)) best = other;
+    rot_to_rvec(best.R, rvec);
+    tvec[0] = best.t[0]; tvec[1] = best.t[1]; tvec[2] = best.t[2];
+    if (quat) rot_to_quat(best.R, quat);
+    const double chk = rvec[0] + rvec[1] + rvec[2] + tvec[0] + tvec[1] + tvec[2];
+    return chk == chk && fabs(chk) < 1e300;
+}
+
+__global__ void pnp_only_kernel(PnpConst c, const float *pts, int n, int armor_size, double *rvec, double *tvec, int32_t *ok)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+    const bool good = solve_pnp_ippe(c, pts + 8 * i, armor_size, r, t, nullptr);
+    for (int k = 0; k < 3; k++) { rvec[3 * i + k] = r[k]; tvec[3 * i + k] = t[k]; }
+    ok[i] = good ? 1 : 0;
+}
+
+void launch_pnp_only(const PnpConst &c, const float *pts, int n, int armor_size, double *rvec, double *tvec, int32_t *ok, hipStream_t s)
+{
+    hipLaunchKernelGGL(pnp_only_kernel, dim3((n + 63) / 64), dim3(64), 0, s, c, pts, n, armor_size, rvec, tvec, ok);
+}
+
+// ---------------------------------------------------------------------------
+// One workgroup (1024 lanes) per frame: bitonic sort of the candidate keys in
+// LDS, blocked greedy NMS on wave 0, then one lane per survivor for keypoints,
+// output scaling and PnP.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
+{
+    __shared__ unsigned long long skeys[kCandCap];          // 64 KiB
+    __shared__ f32x4 kept_box[kMaxDetCap];
+    __shared__ int kept_cls[kMaxDetCap];
+    __shared__ unsigned long long kept_key[kMaxDetCap];
+    __shared__ int s_kept;
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n_total = a.counts[b];
+    const int n_stored = n_total < kCandCap ? n_total : kCandCap;
+    int npow = 64;
+    while (npow < n_stored) npow <<= 1;
+    const unsigned long long *gk = a.keys + (size_t)b * kCandCap;
+    for (int i = tid; i < npow; i += blockDim.x) skeys[i] = i < n_stored ? gk[i] : 0ull;
+    __syncthreads();
+    // bitonic sort, descending
+    for (int k = 2; k <= npow; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = skeys[i], y = skeys[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { skeys[i] = y; skeys[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int n = n_stored < a.pre_nms_cap ? n_stored : a.pre_nms_cap;
+
+    if (tid < 64) {
+        const int lane = tid;
+        int kept = 0;
+        const f32x4 *boxes = reinterpret_cast<const f32x4 *>(a.boxes) + (size_t)b * a.A;
+        for (int start = 0; start < n && kept < a.max_det; start += 64) {
+            const int idx = start + lane;
+            const bool valid = idx < n;
+            const unsigned long long key = valid ? skeys[idx] : 0ull;
+            const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
+            const int an = valid ? (int)(id / (uint32_t)a.nc) : 0;
+            const int cls = valid ? (int)(id % (uint32_t)a.nc) : -1;
+            const f32x4 box = valid ? boxes[an] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            // phase A: against everything kept so far
+            bool alive = valid;
+            for (int j = 0; j < kept; j++) {
+                if (kept_cls[j] == cls && iou_xyxy(kept_box[j], box) > a.iou_thr) alive = false;
+            }
+            // phase B: who inside this block of 64 suppresses me (only earlier lanes can)
+            unsigned long long sup = 0ull;
+            for (int j = 0; j < 64; j++) {
+                f32x4 bj;
+                bj[0] = __shfl(box[0], j);
+                bj[1] = __shfl(box[1], j);
+                bj[2] = __shfl(box[2], j);
+                bj[3] = __shfl(box[3], j);
+                const int cj = __shfl(cls, j);
+                if (j < lane && cj == cls && cls >= 0 && iou_xyxy(bj, box) > a.iou_thr) sup |= 1ull << j;
+            }
+            // sequential resolve, earliest first
+            unsigned long long A = __ballot(alive);
+            int taken = 0;
+            for (int j = 0; j < 64; j++) {
+                if ((A >> j) & 1ull) {
+                    if (kept + taken >= a.max_det) {
+                        A &= (1ull << j) - 1ull;   // cap reached: drop j and everything after
+                        break;
+                    }
+                    taken++;
+                    const unsigned long long col = __ballot((sup >> j) & 1ull);
+                    A &= ~col;
+                }
+            }
+            if ((A >> lane) & 1ull) {
+                const int pos = kept + __popcll(A & ((1ull << lane) - 1ull));
+                kept_box[pos] = box;
+                kept_cls[pos] = cls;
+                kept_key[pos] = key;
+            }
+            kept += __popcll(A);
+        }
+        if (lane == 0) s_kept = kept;
+    }
+    __syncthreads();
+    const int kept = s_kept;
+    if (tid == 0) {
+        DevFrameOut fo;
+        fo.num_dets = kept;
+        fo.n_candidates = n_total;
+        fo.overflow = n_total > kCandCap ? 1 : 0;
+        fo.pad = 0;
+        a.fout[b] = fo;
+    }
+    // one lane per survivor (spread over waves: lane j*8 of the block keeps fp64 PnP off a single SIMD)
+    if (tid < a.max_det) {
+        DevDet d;
+        const int j = tid;
+        if (j < kept) {
+            const f32x4 box = kept_box[j];
+            const unsigned long long key = kept_key[j];
+            const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
+            const int an = (int)(id / (uint32_t)a.nc);
+            const float logit = unorderable((uint32_t)(key >> 32));
+            d.score = 1.0f / (1.0f + irmv_expf(-logit));
+            d.cls = kept_cls[j];
+            d.anchor = an;
+            int ix, iy, s, lvl, rin;
+            anchor_geom(an, a.net, ix, iy, s, lvl, rin);
+            const float axm = ((float)ix + 0.5f) - 0.5f, aym = ((float)iy + 0.5f) - 0.5f, sf = (float)s;
+            const float *kp = head_rec(a, b, lvl, rin) + kKptOff;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                d.box_net[i] = box[i];
+                const float off = (i & 1) ? a.off_y : a.off_x, sc = (i & 1) ? a.scale_y : a.scale_x;
+                d.xyxy[i] = (box[i] - off) * sc;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float kx = 0.f, ky = 0.f;
+                if (2 * q + 1 < a.nk) {
+                    kx = (2.0f * kp[2 * q] + axm) * sf;
+                    ky = (2.0f * kp[2 * q + 1] + aym) * sf;
+                }
+                d.kpts_net[2 * q] = kx;
+                d.kpts_net[2 * q + 1] = ky;
+                d.kpts[2 * q] = (kx - a.off_x) * a.scale_x;
+                d.kpts[2 * q + 1] = (ky - a.off_y) * a.scale_y;
+            }
+            for (int i = 0; i < 3; i++) { d.rvec[i] = 0.0; d.tvec[i] = 0.0; }
+            d.quat[0] = d.quat[1] = d.quat[2] = 0.0; d.quat[3] = 1.0;
+            d.pnp_ok = 0;
+            if (a.nk >= 8) d.pnp_ok = solve_pnp_ippe(a.pnp, d.kpts, a.armor_size, d.rvec, d.tvec, d.quat) ? 1 : 0;
+        } else {
+            // EfficientNMS zero-pads its outputs
+            unsigned char *z = reinterpret_cast<unsigned char *>(&d);
+            for (unsigned i = 0; i < sizeof(DevDet); i++) z[i] = 0;
+        }
+        a.dets[(size_t)b * a.max_det + j] = d;
+    }
+}
+
+void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(nms_pnp_kernel, dim3(batch), dim3(1024), 0, s, a);
+}
+
+}  // namespace irmv

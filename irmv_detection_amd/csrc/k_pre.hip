@@ -1,0 +1,145 @@
+// Frame preprocess and the stem conv for gfx950.
+//
+// Replaces the reference's four NPP launches (src/yolo_engine.cpp:179-200:
+// nppiMirror -> nppiResize -> nppiScale -> nppiCopy packed->planar, ~29 MB of
+// device traffic per frame) with ONE pass: every source row is read once per use
+// with 16-byte coalesced loads into LDS, the 180-degree rotation is folded into
+// the tap indices, and the result is written as fp16 NHWC4 (8 bytes per pixel,
+// the layout model.0.conv consumes).  HBM-bound: 3.93 MB read + 3.28 MB written
+// per 1280x1024 frame.
+#include "irmv_common.hpp"
+
+namespace irmv {
+
+constexpr int kCoefBits = 11;
+constexpr int kCoefOne = 1 << kCoefBits;
+constexpr int kMaxRowBytes = 4096 * 3;
+
+__global__ __launch_bounds__(256) void preprocess_kernel(PreArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t rows[2][kMaxRowBytes];
+    const int dy = blockIdx.x, b = blockIdx.y;
+    const AxisTap ty = a.ty[dy];
+    const int row_bytes = a.sw * 3;
+    const uint8_t *src = a.src + (size_t)b * a.src_slot_bytes;
+    half_t *dst = a.dst + ((size_t)b * a.net + dy) * a.net * 4;
+    const half_t padv = (half_t)(114.0f / 255.0f);
+
+    if (ty.i0 >= 0) {
+        const uint8_t *r0 = src + (size_t)ty.i0 * row_bytes;
+        const uint8_t *r1 = src + (size_t)ty.i1 * row_bytes;
+        if ((row_bytes & 15) == 0) {
+            const int nvec = row_bytes >> 4;
+            for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
+                reinterpret_cast<uint4 *>(rows[0])[i] = reinterpret_cast<const uint4 *>(r0)[i];
+                reinterpret_cast<uint4 *>(rows[1])[i] = reinterpret_cast<const uint4 *>(r1)[i];
+            }
+        } else {
+            for (int i = threadIdx.x; i < row_bytes; i += blockDim.x) {
+                rows[0][i] = r0[i];
+                rows[1][i] = r1[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint32_t wy = (uint32_t)ty.w1;
+    for (int dx = threadIdx.x; dx < a.net; dx += blockDim.x) {
+        const AxisTap tx = a.tx[dx];
+        half4 o;
+        if (ty.i0 < 0 || tx.i0 < 0) {
+            o = (half4){padv, padv, padv, (half_t)0.0f};
+        } else {
+            const uint32_t wx = (uint32_t)tx.w1;
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const uint32_t p00 = rows[0][tx.i0 * 3 + c], p01 = rows[0][tx.i1 * 3 + c];
+                const uint32_t p10 = rows[1][tx.i0 * 3 + c], p11 = rows[1][tx.i1 * 3 + c];
+                const uint32_t top = (kCoefOne - wx) * p00 + wx * p01;
+                const uint32_t bot = (kCoefOne - wx) * p10 + wx * p11;
+                const uint32_t acc = (kCoefOne - wy) * top + wy * bot;
+                const uint32_t q = (acc + (1u << (2 * kCoefBits - 1))) >> (2 * kCoefBits);
+                v[c] = (float)q / 255.0f;
+            }
+            if (a.swap_rb) { const float t = v[0]; v[0] = v[2]; v[2] = t; }
+            o = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)0.0f};
+        }
+        *reinterpret_cast<half4 *>(dst + (size_t)dx * 4) = o;
+    }
+}
+
+void launch_preprocess(const PreArgs &a, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(preprocess_kernel, dim3(a.net, batch), dim3(256), 0, s, a);
+}
+
+// dst(x, y) = src(sw-1-x, sh-1-y): the frame get_rotated_image() exposes.
+__global__ __launch_bounds__(256) void rotate180_kernel(const uint8_t *src, uint8_t *dst, int sw, int sh)
+{
+    const size_t npx = (size_t)sw * sh;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t q = npx - 1 - p;
+        dst[p * 3 + 0] = src[q * 3 + 0];
+        dst[p * 3 + 1] = src[q * 3 + 1];
+        dst[p * 3 + 2] = src[q * 3 + 2];
+    }
+}
+
+void launch_rotate180(const uint8_t *src, uint8_t *dst, int sw, int sh, hipStream_t s)
+{
+    hipLaunchKernelGGL(rotate180_kernel, dim3(2048), dim3(256), 0, s, src, dst, sw, sh);
+}
+
+// model.0.conv (3x3 stride 2, 3 -> 16, SiLU).  K = 27 is too thin for MFMA
+// (SURVEY.md section 7 item 4): one lane per output pixel, the 432 weights are
+// wave-uniform and ride in SGPRs.
+__global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a)
+{
+    const int Ho = a.net >> 1;
+    const int total = a.batch * Ho * Ho;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int b = p / (Ho * Ho), rem = p - b * Ho * Ho, oy = rem / Ho, ox = rem - oy * Ho;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; o++) acc[o] = a.b[o];
+    const half_t *xb = a.x + (size_t)b * a.net * a.net * 4;
+#pragma unroll
+    for (int kh = 0; kh < 3; kh++) {
+        const int iy = oy * 2 - 1 + kh;
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+            const int ix = ox * 2 - 1 + kw;
+            half4 xv = (half4){0, 0, 0, 0};
+            if ((unsigned)iy < (unsigned)a.net && (unsigned)ix < (unsigned)a.net)
+                xv = *reinterpret_cast<const half4 *>(xb + ((size_t)iy * a.net + ix) * 4);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float xf = (float)xv[c];
+                const float *w = a.w + ((kh * 3 + kw) * 3 + c) * 16;
+#pragma unroll
+                for (int o = 0; o < 16; o++) acc[o] = fmaf(xf, w[o], acc[o]);
+            }
+        }
+    }
+    half8 o0, o1;
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        const float v0 = acc[o], v1 = acc[o + 8];
+        o0[o] = (half_t)(v0 * __frcp_rn(1.0f + __expf(-v0)));
+        o1[o] = (half_t)(v1 * __frcp_rn(1.0f + __expf(-v1)));
+    }
+    half_t *y = a.y + (size_t)p * 16;
+    *reinterpret_cast<half8 *>(y) = o0;
+    *reinterpret_cast<half8 *>(y + 8) = o1;
+}
+
+void launch_conv0(const Conv0Args &a, hipStream_t s)
+{
+    const int Ho = a.net >> 1;
+    const int total = a.batch * Ho * Ho;
+    hipLaunchKernelGGL(conv0_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace irmv
