@@ -129,11 +129,11 @@ uint8_t *irmv_engine_src_buffer(irmv_engine *e, int slot);
  * frame in HBM, and for HBM-resident benchmarking). */
 void *irmv_engine_src_device_buffer(irmv_engine *e, int slot);
 
-#define IRMV_SUBMIT_H2D 1u /* copy pinned slots -> HBM first (async, in the captured step) */
+#define IRMV_SUBMIT_H2D 1u /* copy pinned slots -> HBM first (async, same stream, ahead of the captured kernels) */
 
-/* Launch the captured step {[H2D] preprocess -> network -> decode -> NMS ->
- * keypoints -> PnP -> D2H} for slots [first, first+count) as one hipGraph on the
- * engine's stream; returns immediately.  count == 1 is the reference's per-slot
+/* Enqueue one step for slots [first, first+count) on the engine's stream:
+ * [async H2D of the frames] -> ONE hipGraph {preprocess -> network -> decode ->
+ * NMS -> keypoints -> PnP} -> async D2H of the results; returns immediately.  count == 1 is the reference's per-slot
  * detect(); count > 1 batches independent frames through every kernel. */
 int irmv_engine_submit(irmv_engine *e, int first_slot, int count, uint32_t flags);
 int irmv_engine_wait(irmv_engine *e);

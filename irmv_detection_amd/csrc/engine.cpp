@@ -7,8 +7,9 @@
 //     reference's cudaMallocManaged source buffer (:60-61) + TripleBuffer;
 //   * one set of weights per device shared by all slots (the reference builds
 //     three full engines, src/irm_detector.cpp:35-38);
-//   * the whole step {H2D, preprocess, ~73 conv launches, pool, decode, NMS+PnP,
-//     D2H} is captured once per (first_slot, count) into a hipGraph (:102-107)
+//   * the kernels of a step {preprocess, ~73 conv launches, pool, decode, NMS+PnP}
+//     are captured once per (first_slot, count) into a hipGraph (:102-107),
+//     bracketed by the async H2D frame copy and D2H result copy on the same stream,
 //     and `count` independent frames ride through every kernel as the batch
 //     dimension of its GEMM M axis, which is what fills 256 CUs;
 //   * no host work between launch and results except the final struct copy
@@ -650,9 +651,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
 {
     hipStream_t s = e->stream;
     const int net = e->cfg.net_size;
-    if (!post_only && (flags & IRMV_SUBMIT_H2D))
-        HIP_TRY(hipMemcpyAsync(e->src_dev + (size_t)first * e->frame_bytes, e->src_host + (size_t)first * e->frame_bytes,
-                               e->frame_bytes * count, hipMemcpyHostToDevice, s));
+    (void)flags;
     HIP_TRY(hipMemsetAsync(e->counts + first, 0, (size_t)count * 4, s));
     const PostArgs pa = post_args(e, first);
     for (const Op &op : e->ops) {
@@ -702,10 +701,24 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             ev->push_back(r);
         }
     }
+    return IRMV_OK;
+}
+
+// The frame upload and the result download bracket the captured kernels as plain
+// async copies on the same stream (pinned memory both ways).
+static int copy_in(irmv_engine *e, int first, int count)
+{
+    HIP_TRY(hipMemcpyAsync(e->src_dev + (size_t)first * e->frame_bytes, e->src_host + (size_t)first * e->frame_bytes,
+                           e->frame_bytes * count, hipMemcpyHostToDevice, e->stream));
+    return IRMV_OK;
+}
+
+static int copy_out(irmv_engine *e, int first, int count)
+{
     HIP_TRY(hipMemcpyAsync(e->dets_host + (size_t)first * e->cfg.max_det, e->dets_dev + (size_t)first * e->cfg.max_det,
-                           (size_t)count * e->cfg.max_det * sizeof(DevDet), hipMemcpyDeviceToHost, s));
+                           (size_t)count * e->cfg.max_det * sizeof(DevDet), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(e->fout_host + first, e->fout_dev + first, (size_t)count * sizeof(DevFrameOut),
-                           hipMemcpyDeviceToHost, s));
+                           hipMemcpyDeviceToHost, e->stream));
     return IRMV_OK;
 }
 
@@ -740,8 +753,10 @@ extern "C" int irmv_engine_submit(irmv_engine *e, int first, int count, uint32_t
     TRY(check_range(e, first, count));
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipGraphExec_t ge;
-    TRY(get_graph(e, first, count, flags & IRMV_SUBMIT_H2D, false, &ge));
+    TRY(get_graph(e, first, count, 0, false, &ge));
+    if (flags & IRMV_SUBMIT_H2D) TRY(copy_in(e, first, count));
     HIP_TRY(hipGraphLaunch(ge, e->stream));
+    TRY(copy_out(e, first, count));
     return IRMV_OK;
 }
 
@@ -752,6 +767,7 @@ extern "C" int irmv_engine_run_post(irmv_engine *e, int first, int count)
     hipGraphExec_t ge;
     TRY(get_graph(e, first, count, 0, true, &ge));
     HIP_TRY(hipGraphLaunch(ge, e->stream));
+    TRY(copy_out(e, first, count));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return IRMV_OK;
 }
@@ -916,6 +932,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
     HIP_TRY(hipSetDevice(e->cfg.device));
     std::vector<EvRec> ev;
     TRY(enqueue_step(e, first, count, 0, false, &ev));
+    TRY(copy_out(e, first, count));
     HIP_TRY(hipStreamSynchronize(e->stream));
     int k = 0;
     for (size_t i = 0; i < ev.size(); i++) {
