@@ -1,0 +1,142 @@
+// irmv_detection::YoloEngine on MI355X -- header-only facade over the C ABI of
+// libirmv_hip.so with the reference's public interface (reference
+// include/irmv_detection/yolo_engine.hpp:16-73): same constructor arguments,
+// detect(), visualize_bboxes(), get_profiling_time(), get_rotated_image(),
+// get_src_image_buffer().  Code written against the reference class
+// (src/irm_detector.cpp:35-38,181-183; test/yolo_test.cpp:19-30,58-82) compiles
+// unchanged against this one.
+//
+// Deliberate deviations (documented in DESIGN.md):
+//  * HIP failures throw std::runtime_error (the reference checks no return code);
+//  * the per-instance scale factors are per instance (the reference's are
+//    function-local statics, src/yolo_engine.cpp:155-156);
+//  * the source slot is never modified: rotation is folded into the sampling, so
+//    get_rotated_image() materialises the rotated frame on demand (GPU kernel);
+//  * a missing model file prints the reference's message and exit(0)s like
+//    src/yolo_engine.cpp:38-39, but the file looked for is "<stem>.irmw".
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstdlib>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "irmv_detection/armor.hpp"
+#include "irmv_detection/cv_compat.hpp"
+#include "irmv_hip.h"
+
+namespace irmv_detection
+{
+class YoloEngine
+{
+public:
+  struct bbox
+  {
+    std::array<float, 4> xyxy;
+    float score;
+    ArmorClass class_id;
+
+    bool operator==(const bbox & o) const { return xyxy == o.xyxy && score == o.score && class_id == o.class_id; }
+  };
+
+  YoloEngine(const std::string & onnx_file_path, cv::Size src_image_size, bool enable_profiling = false)
+  : src_image_size_(src_image_size), enable_profiling_(enable_profiling)
+  {
+    irmv_engine_cfg cfg;
+    irmv_engine_cfg_default(&cfg);
+    cfg.src_width = src_image_size.width;
+    cfg.src_height = src_image_size.height;
+    cfg.num_slots = 1;  // one engine per TripleBuffer slot, like the reference node
+    cfg.weights_path = onnx_file_path.c_str();
+    const int rc = irmv_engine_create(&cfg, &engine_);
+    if (rc == IRMV_ERR_MODEL) {
+      std::cout << "Please convert the model to <stem>.irmw first (" << irmv_last_error() << ")." << std::endl;
+      std::exit(0);
+    }
+    if (rc != IRMV_OK) throw std::runtime_error(std::string("YoloEngine: ") + irmv_last_error());
+    src_image_buffer_ = irmv_engine_src_buffer(engine_, 0);
+    rotated_ = cv::Mat(src_image_size.height, src_image_size.width, CV_8UC3);
+    dets_.resize(static_cast<size_t>(irmv_engine_max_det(engine_)));
+    for (int i = 0; i < 50; i++) detect();  // warm-up, as src/yolo_engine.cpp:114-116
+  }
+
+  ~YoloEngine() { irmv_engine_destroy(engine_); }
+  YoloEngine(const YoloEngine &) = delete;
+  YoloEngine & operator=(const YoloEngine &) = delete;
+
+  std::vector<bbox> detect()
+  {
+    int n = 0;
+    const int rc = irmv_engine_detect(engine_, 0, dets_.data(), static_cast<int>(dets_.size()), &n);
+    if (rc != IRMV_OK && rc != IRMV_ERR_OVERFLOW) throw std::runtime_error(std::string("YoloEngine::detect: ") + irmv_last_error());
+    rotated_valid_ = false;
+    std::vector<bbox> out;
+    out.reserve(static_cast<size_t>(n));
+    for (int i = 0; i < n; i++) {
+      const irmv_det & d = dets_[static_cast<size_t>(i)];
+      out.push_back(bbox{{d.xyxy[0], d.xyxy[1], d.xyxy[2], d.xyxy[3]}, d.score, static_cast<ArmorClass>(d.class_id)});
+    }
+    n_last_ = n;
+    return out;
+  }
+
+  // The full per-armor result of the last detect(): keypoints and pose, computed on the GPU.
+  const irmv_det * last_detections(int * n) const
+  {
+    *n = n_last_;
+    return dets_.data();
+  }
+
+  void visualize_bboxes(cv::Mat & image, const std::vector<bbox> & bboxes) const
+  {
+    if (image.cols != src_image_size_.width || image.rows != src_image_size_.height) {
+      std::cerr << "[YoloEngine::visualize_bboxes] Image size mismatch" << std::endl;
+      return;
+    }
+    for (const auto & b : bboxes) {
+      const bool blue = armor_class_name(b.class_id)[0] == 'B';
+      draw_rect(image, int(b.xyxy[0]), int(b.xyxy[1]), int(b.xyxy[2]), int(b.xyxy[3]), blue ? 0 : 255, 0, blue ? 255 : 0);
+    }
+  }
+
+  double get_profiling_time() const { return enable_profiling_ ? irmv_engine_last_detect_ms(engine_) : 0.0; }
+
+  const cv::Mat & get_rotated_image() const
+  {
+    if (!rotated_valid_) {
+      if (irmv_engine_rotated_image(engine_, 0, rotated_.data) != IRMV_OK)
+        throw std::runtime_error(std::string("YoloEngine::get_rotated_image: ") + irmv_last_error());
+      rotated_valid_ = true;
+    }
+    return rotated_;
+  }
+
+  uint8_t * get_src_image_buffer() const { return src_image_buffer_; }
+
+private:
+  static void draw_rect(cv::Mat & img, int x1, int y1, int x2, int y2, int c0, int c1, int c2)
+  {
+    auto put = [&](int x, int y) {
+      if (x < 0 || y < 0 || x >= img.cols || y >= img.rows) return;
+      uint8_t * p = img.data + (size_t(y) * img.cols + x) * 3;
+      p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2);
+    };
+    for (int t = 0; t < 2; t++) {
+      for (int x = x1; x <= x2; x++) { put(x, y1 + t); put(x, y2 - t); }
+      for (int y = y1; y <= y2; y++) { put(x1 + t, y); put(x2 - t, y); }
+    }
+  }
+
+  irmv_engine * engine_ = nullptr;
+  cv::Size src_image_size_;
+  bool enable_profiling_ = false;
+  uint8_t * src_image_buffer_ = nullptr;
+  mutable cv::Mat rotated_;
+  mutable bool rotated_valid_ = false;
+  std::vector<irmv_det> dets_;
+  int n_last_ = 0;
+};
+}  // namespace irmv_detection
