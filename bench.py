@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--frames-per-step", type=int, default=16)
     ap.add_argument("--src", default="1280x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--cpu-frames", type=int, default=96)
     return ap.parse_args()
 
 
