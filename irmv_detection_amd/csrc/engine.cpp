@@ -103,13 +103,16 @@ enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_DECODE, OP_NMS };
 struct Op {
     OpKind kind;
     std::string layer;
-    ConvCfg cfg{};
+    ConvCfg cfg{};      // tile shape for full batched steps (count == num_slots)
+    ConvCfg cfg_one{};  // tile shape for single-frame steps (latency mode)
+    char kname_one[48] = {0};
     SegRef s0, s1;
     int Hin = 0, Win = 0, Hout = 0, Wout = 0, cin = 0, cout = 0, cout_pad = 0, ksteps = 0;
     int out_t = -1, out_coff = 0, res_t = -1, res_coff = 0;
     half_t *w_packed = nullptr;
     float *bias = nullptr;
     double flops = 0, bytes = 0;  // per frame
+    bool pair = false;
     char kname[48] = {0};
 };
 
@@ -137,12 +140,15 @@ struct irmv_engine {
     std::vector<Op> ops;
     std::vector<void *> dev_allocs;
     int head_t[3] = {-1, -1, -1};
+    float *head_all = nullptr;
+    PnpConst *pnp_dev = nullptr;
     float *boxes = nullptr;
     unsigned long long *keys = nullptr;
     int *counts = nullptr;
     DevDet *dets_dev = nullptr, *dets_host = nullptr;
     DevFrameOut *fout_dev = nullptr, *fout_host = nullptr;
-    float *conv0_w = nullptr, *conv0_b = nullptr;
+    half_t *conv0_w = nullptr;
+    float *conv0_b = nullptr;
     PostArgs post{};
     std::map<GraphKey, hipGraphExec_t> graphs;
     double last_detect_ms = 0;
@@ -206,7 +212,8 @@ static int pack_conv(irmv_engine *e, const LayerW &l, Op &op)
     const int taps = l.k * l.k;
     op.cout_pad = (l.cout + 15) / 16 * 16;
     const int ntiles = op.cout_pad / 16;
-    const bool pair = !op.cfg.out_f32 && (op.cfg.nt % 2 == 0);
+    const bool pair = !op.cfg.out_f32 && (op.cout_pad % 32 == 0);   // independent of the tile shape chosen later
+    op.pair = pair;
     const int cpt = (l.cin + 31) / 32;
     op.ksteps = op.cfg.cin16 ? (taps + 1) / 2 : taps * cpt;
     std::vector<uint16_t> packed((size_t)ntiles * op.ksteps * 512, 0);
@@ -261,7 +268,10 @@ static int add_conv(irmv_engine *e, const std::string &layer, SegRef s0, SegRef 
     const long m_batch = (long)e->cfg.num_slots * op.Hout * op.Wout;
     const long blocks_mt2 = ((m_batch + 127) / 128) * (cout_pad / (16 * op.cfg.nt));
     op.cfg.mt = blocks_mt2 >= 512 ? 2 : 1;
+    op.cfg_one = op.cfg;
+    op.cfg_one.mt = 1;
     conv_cfg_name(op.cfg, op.kname, sizeof op.kname);
+    conv_cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one);
     op.flops = 2.0 * op.Hout * op.Wout * (double)l->cout * l->cin * l->k * l->k;
     op.bytes = 2.0 * ((double)Hin * Win * l->cin / ((s0.shift || s1.shift) ? 1.0 : 1.0)) +
                (double)op.Hout * op.Wout * l->cout * (ot.f32 ? 4.0 : 2.0) + 2.0 * l->cout * l->cin * l->k * l->k;
@@ -313,6 +323,8 @@ static void axis_taps(std::vector<AxisTap> &out, int dn_total, int sn, int dn, i
         out[d] = AxisTap{a, b, w, 0};
     }
 }
+
+static int autotune_convs(irmv_engine *e);
 
 static int build_engine(irmv_engine *e)
 {
@@ -372,17 +384,23 @@ static int build_engine(irmv_engine *e)
         const LayerW *l = find_layer(e, "model.0.conv");
         if (!l || l->cin != 3 || l->cout != 16 || l->k != 3 || l->stride != 2)
             return fail(IRMV_ERR_MODEL, "model.0.conv missing or not 3x3 s2 3->16");
-        std::vector<float> w(27 * 16), b(16);
-        for (int o = 0; o < 16; o++) {
-            b[o] = l->b[o];
-            for (int t = 0; t < 9; t++)
-                for (int ci = 0; ci < 3; ci++) w[(t * 3 + ci) * 16 + o] = half_bits_to_float(l->w[(o * 9 + t) * 3 + ci]);
-        }
-        TRY(dev_alloc(e, (void **)&e->conv0_w, w.size() * 4));
+        // A fragments of the single 16-channel tile: lane (g, r) of k-step s holds channel r,
+        // k = 32 s + 8 g + j  ->  kernel row kh = 2 s + (g >> 1), tap slot kw = 2 (g & 1) + (j >> 2), channel j & 3
+        std::vector<uint16_t> w(2 * 64 * 8, 0);
+        std::vector<float> b(16);
+        for (int o = 0; o < 16; o++) b[o] = l->b[o];
+        for (int ks = 0; ks < 2; ks++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int g = lane >> 4, o = lane & 15;
+                    const int kh = 2 * ks + (g >> 1), kw = 2 * (g & 1) + (j >> 2), ci = j & 3;
+                    if (kh < 3 && kw < 3 && ci < 3) w[((size_t)ks * 64 + lane) * 8 + j] = l->w[(o * 9 + kh * 3 + kw) * 3 + ci];
+                }
+        TRY(dev_alloc(e, (void **)&e->conv0_w, w.size() * 2));
         TRY(dev_alloc(e, (void **)&e->conv0_b, b.size() * 4));
-        HIP_TRY(hipMemcpy(e->conv0_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->conv0_w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(e->conv0_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
-        Op op; op.kind = OP_CONV0; op.layer = "model.0.conv"; snprintf(op.kname, sizeof op.kname, "conv0_valu");
+        Op op; op.kind = OP_CONV0; op.layer = "model.0.conv"; snprintf(op.kname, sizeof op.kname, "conv0_mfma");
         op.flops = 2.0 * s2 * s2 * 16 * 27;
         op.bytes = (double)net * net * 8 + (double)s2 * s2 * 32 + 27 * 16 * 2;
         e->ops.push_back(op);
@@ -413,9 +431,20 @@ static int build_engine(irmv_engine *e)
         e->lvl_hw[i] = PS[i] * PS[i];
         e->lvl_base[i] = base;
         base += e->lvl_hw[i];
-        TRY(new_tensor(e, "head." + std::to_string(i), PS[i], PS[i], kHeadRec, true, &e->head_t[i]));
     }
     e->A = base;
+    TRY(dev_alloc(e, (void **)&e->head_all, (size_t)S * e->A * kHeadRec * 4));
+    HIP_TRY(hipMemset(e->head_all, 0, (size_t)S * e->A * kHeadRec * 4));
+    for (int i = 0; i < 3; i++) {   // per-level views [slot][H*W][kHeadRec] into the one head allocation
+        Tensor t;
+        t.name = "head." + std::to_string(i);
+        t.H = PS[i]; t.W = PS[i]; t.C = kHeadRec; t.f32 = true;
+        t.slot_elems = (size_t)PS[i] * PS[i] * kHeadRec;
+        t.base = e->head_all + (size_t)e->lvl_base[i] * S * kHeadRec;
+        e->head_t[i] = (int)e->tensors.size();
+        e->tensor_idx[t.name] = e->head_t[i];
+        e->tensors.push_back(t);
+    }
     const char *br[3] = {"cv2", "cv3", "cv4"};
     const int mid[3] = {64, 64, 16}, off[3] = {0, kClsOff, kKptOff};
     for (int b = 0; b < (e->nk > 0 ? 3 : 2); b++)
@@ -464,12 +493,16 @@ static int build_engine(irmv_engine *e)
         p.off_y = (float)py;
     }
     p.armor_size = c.armor_size;
-    p.pnp.fx = c.camera_matrix[0]; p.pnp.fy = c.camera_matrix[4];
-    p.pnp.cx = c.camera_matrix[2]; p.pnp.cy = c.camera_matrix[5];
-    p.pnp.k1 = c.dist_coeffs[0]; p.pnp.k2 = c.dist_coeffs[1]; p.pnp.p1 = c.dist_coeffs[2];
-    p.pnp.p2 = c.dist_coeffs[3]; p.pnp.k3 = c.dist_coeffs[4];
-    p.pnp.hy[0] = 135.0 / 2.0 / 1000.0; p.pnp.hy[1] = 225.0 / 2.0 / 1000.0;   // src/pnp_solver.cpp:18-21
-    p.pnp.hz[0] = p.pnp.hz[1] = 55.0 / 2.0 / 1000.0;
+    PnpConst pc;
+    pc.fx = c.camera_matrix[0]; pc.fy = c.camera_matrix[4];
+    pc.cx = c.camera_matrix[2]; pc.cy = c.camera_matrix[5];
+    pc.k1 = c.dist_coeffs[0]; pc.k2 = c.dist_coeffs[1]; pc.p1 = c.dist_coeffs[2];
+    pc.p2 = c.dist_coeffs[3]; pc.k3 = c.dist_coeffs[4];
+    pc.hy[0] = 135.0 / 2.0 / 1000.0; pc.hy[1] = 225.0 / 2.0 / 1000.0;   // src/pnp_solver.cpp:18-21
+    pc.hz[0] = pc.hz[1] = 55.0 / 2.0 / 1000.0;
+    TRY(dev_alloc(e, (void **)&e->pnp_dev, sizeof(PnpConst)));
+    HIP_TRY(hipMemcpy(e->pnp_dev, &pc, sizeof pc, hipMemcpyHostToDevice));
+    p.pnp = e->pnp_dev;
     HIP_TRY(hipDeviceSynchronize());
     return IRMV_OK;
 }
@@ -576,6 +609,8 @@ extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
     if (rc) return rc;
     rc = build_engine(e.get());
     if (rc) return rc;
+    rc = autotune_convs(e.get());
+    if (rc) return rc;
     *out = e.release();
     return IRMV_OK;
 }
@@ -595,6 +630,55 @@ extern "C" void *irmv_engine_src_device_buffer(irmv_engine *e, int slot)
 {
     if (!e || slot < 0 || slot >= e->cfg.num_slots) return nullptr;
     return e->src_dev + (size_t)slot * e->frame_bytes;
+}
+
+// ---- per-layer tile autotuner ---------------------------------------------------
+// Every conv layer is timed at its real shape with each (MT, NT) tile the kernel
+// family offers and keeps the fastest, once for full batched steps and once for
+// single-frame steps.  All tiles walk K in the same order, so the choice never
+// changes a single output bit (tests/test_gpu_engine.py::test_tile_choice_is_bitwise_neutral).
+static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int count, ConvArgs &a);
+
+static int autotune_convs(irmv_engine *e)
+{
+    const char *env = getenv("IRMV_AUTOTUNE");
+    if (env && env[0] == '0') return IRMV_OK;
+    hipEvent_t ea, eb;
+    HIP_TRY(hipEventCreate(&ea));
+    HIP_TRY(hipEventCreate(&eb));
+    const int counts[2] = {e->cfg.num_slots, 1};
+    for (Op &op : e->ops) {
+        if (op.kind != OP_CONV) continue;
+        for (int pass = 0; pass < (e->cfg.num_slots > 1 ? 2 : 1); pass++) {
+            ConvArgs a;
+            fill_conv_args(e, op, 0, counts[pass], a);
+            float best = 1e30f;
+            ConvCfg best_cfg = pass == 0 ? op.cfg : op.cfg_one;
+            for (int mt = 1; mt <= 4; mt *= 2)
+                for (int nt = 1; nt <= 4; nt *= 2) {
+                    if (op.cout_pad % (16 * nt) != 0) continue;
+                    ConvCfg c = op.cfg;
+                    c.mt = mt; c.nt = nt;
+                    bool ok = true;
+                    for (int i = 0; i < 2 && ok; i++) ok = launch_conv(c, a, e->stream);
+                    if (!ok) continue;
+                    HIP_TRY(hipEventRecord(ea, e->stream));
+                    for (int i = 0; i < 6; i++) launch_conv(c, a, e->stream);
+                    HIP_TRY(hipEventRecord(eb, e->stream));
+                    HIP_TRY(hipEventSynchronize(eb));
+                    float ms = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&ms, ea, eb));
+                    if (ms < best) { best = ms; best_cfg = c; }
+                }
+            if (pass == 0) { op.cfg = best_cfg; conv_cfg_name(op.cfg, op.kname, sizeof op.kname); }
+            else { op.cfg_one = best_cfg; conv_cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
+            if (e->cfg.num_slots == 1) { op.cfg_one = op.cfg; conv_cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
+        }
+    }
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    HIP_TRY(hipGetLastError());
+    return IRMV_OK;
 }
 
 // ---- step execution ------------------------------------------------------------
@@ -631,13 +715,15 @@ static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int co
     }
     a.cout_pad = op.cout_pad;
     a.ksteps = op.ksteps;
+    a.pair = op.pair ? 1 : 0;
 }
 
 static PostArgs post_args(const irmv_engine *e, int first)
 {
     PostArgs p = e->post;
-    for (int i = 0; i < 3; i++) p.head[i] = static_cast<const float *>(e->tensors[e->head_t[i]].slot(first));
-    for (int i = 0; i < 3; i++) { p.lvl_hw[i] = e->lvl_hw[i]; p.lvl_base[i] = e->lvl_base[i]; }
+    p.head_all = e->head_all;
+    p.slots_total = e->cfg.num_slots;
+    p.first = first;
     p.boxes = e->boxes + (size_t)first * e->A * 4;
     p.keys = e->keys + (size_t)first * kCandCap;
     p.counts = e->counts + first;
@@ -684,7 +770,8 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         case OP_CONV: {
             ConvArgs a;
             fill_conv_args(e, op, first, count, a);
-            if (!launch_conv(op.cfg, a, s)) return fail(IRMV_ERR_ARG, std::string("no conv kernel for ") + op.kname + " (" + op.layer + ")");
+            const ConvCfg &cc = (count == 1 && e->cfg.num_slots > 1) ? op.cfg_one : op.cfg;
+            if (!launch_conv(cc, a, s)) return fail(IRMV_ERR_ARG, std::string("no conv kernel for ") + op.kname + " (" + op.layer + ")");
             break;
         }
         case OP_POOL: {
@@ -944,7 +1031,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
             const Op &op = e->ops[i];
             irmv_kernel_stat &st = stats[k];
             memset(&st, 0, sizeof st);
-            snprintf(st.name, sizeof st.name, "%s", op.kname);
+            snprintf(st.name, sizeof st.name, "%s", (count == 1 && e->cfg.num_slots > 1 && op.kind == OP_CONV) ? op.kname_one : op.kname);
             snprintf(st.layer, sizeof st.layer, "%s", op.layer.c_str());
             st.flops = op.flops * count;
             st.bytes = op.bytes * count;

@@ -34,11 +34,11 @@ struct PreArgs {
 void launch_preprocess(const PreArgs &a, int batch, hipStream_t s);
 void launch_rotate180(const uint8_t *src, uint8_t *dst, int sw, int sh, hipStream_t s);
 
-// model.0.conv: 3x3 s2, 3(+1 pad) -> 16, SiLU, VALU kernel
+// model.0.conv: 3x3 s2, 3(+1 pad) -> 16, SiLU
 struct Conv0Args {
     const half_t *x;      // [B][net][net][4]
     half_t *y;            // [B][net/2][net/2][16]
-    const float *w;       // [27][16] (tap, cin, cout)
+    const half_t *w;      // packed MFMA A fragments [2 k-steps][64 lanes][8]; k = kh*16 + slot*4 + c
     const float *b;       // [16]
     int net, batch;
 };
@@ -66,6 +66,7 @@ struct ConvArgs {
     int res_ld;
     int cout_pad;       // multiple of 16
     int ksteps;
+    int pair;           // weight rows packed with the paired-tile channel permutation
 };
 
 struct ConvCfg { int ks, stride, mt, nt; bool cin16; int act; bool out_f32; };
@@ -94,8 +95,8 @@ struct PnpConst {
 };
 
 struct PostArgs {
-    const float *head[3];     // per Detect level: [B][H*W][kHeadRec]
-    int lvl_hw[3], lvl_base[3];
+    const float *head_all;    // one allocation: [level][slot (all num_slots)][H*W][kHeadRec]
+    int slots_total, first;   // level block offset = lvl_base * slots_total records; this step starts at slot `first`
     float *boxes;             // [B][A][4]
     unsigned long long *keys; // [B][kCandCap]
     int *counts;              // [B]
@@ -107,7 +108,7 @@ struct PostArgs {
     // parse_output mapping net -> source frame: x_src = (x - off_x) * scale_x
     float scale_x, scale_y, off_x, off_y;
     int armor_size;
-    PnpConst pnp;
+    const PnpConst *pnp;      // device copy (keeps the kernel-argument struct out of scratch)
 };
 void launch_decode(const PostArgs &a, int batch, hipStream_t s);
 void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s);

@@ -19,11 +19,16 @@
 
 namespace irmv {
 
+// Prefetch depth of the register ring: small tiles are latency-bound (few waves per
+// CU on the 20x20 / 40x40 layers), so they keep more k-steps of loads in flight.
+template <int MT, int NT>
+struct PrefetchDepth { static constexpr int value = (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4); };
+
 template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 {
     constexpr int PAD = KS / 2;
-    constexpr bool PAIR = !OUT_F32 && (NT % 2 == 0);
+    constexpr int PF = PrefetchDepth<MT, NT>::value;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
     const int tile0 = (blockIdx.x * 4 + wave) * MT;
@@ -55,119 +60,135 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     const int H1 = a.Hin >> a.s1.shift, W1 = a.Win >> a.s1.shift;
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 
-    if constexpr (CIN16) {
-        // Cin == 16: one k-step of 32 spans TWO filter taps (lanes g<2: tap 2i, g>=2: tap 2i+1)
-        const int c = 8 * (g & 1);
-        for (int ks = 0; ks < a.ksteps; ks++) {
-            const int tap = 2 * ks + (g >> 1);
-            const int kh = tap / KS, kw = tap - kh * KS;
-            half8 bf[MT];
+    // ---- loader state: walks the k-steps in order, PF steps ahead of the MFMAs ----
+    int l_ks = 0, l_tap = 0, l_cc = 0;
+    const half_t *p0[MT], *p1[MT];
+    bool pv[MT];
+    auto set_tap = [&](int tap) {
+        const int kh = tap / KS, kw = tap - kh * KS;
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                const int iy = iy0[mt] + kh, ix = ix0[mt] + kw;
-                const bool v = mv[mt] && tap < KS * KS && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-                bf[mt] = zero8;
-                if (v) bf[mt] = *reinterpret_cast<const half8 *>(a.s0.p + ((size_t)(bb[mt] * H0 + iy) * W0 + ix) * a.s0.ld + c);
-            }
-            half8 af[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) af[nt] = wp[(size_t)(nt * a.ksteps + ks) * 64];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf[mt], acc[mt][nt], 0, 0, 0);
-        }
-    } else {
-        int ks = 0;
-        for (int tap = 0; tap < KS * KS; tap++) {
-            const int kh = tap / KS, kw = tap - kh * KS;
-            const half_t *p0[MT], *p1[MT];
-            bool v[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                const int iy = iy0[mt] + kh, ix = ix0[mt] + kw;
-                v[mt] = mv[mt] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-                const int iyc = v[mt] ? iy : 0, ixc = v[mt] ? ix : 0;
-                p0[mt] = a.s0.p + ((size_t)(bb[mt] * H0 + (iyc >> a.s0.shift)) * W0 + (ixc >> a.s0.shift)) * a.s0.ld;
+        for (int mt = 0; mt < MT; mt++) {
+            const int iy = iy0[mt] + kh, ix = ix0[mt] + kw;
+            pv[mt] = mv[mt] && tap < KS * KS && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const int iyc = pv[mt] ? iy : 0, ixc = pv[mt] ? ix : 0;
+            p0[mt] = a.s0.p + ((size_t)(bb[mt] * H0 + (iyc >> a.s0.shift)) * W0 + (ixc >> a.s0.shift)) * a.s0.ld;
+            if constexpr (!CIN16)
                 p1[mt] = a.s1.p + ((size_t)(bb[mt] * H1 + (iyc >> a.s1.shift)) * W1 + (ixc >> a.s1.shift)) * a.s1.ld;
-            }
-            for (int cc = 0; cc < a.Cin; cc += 32, ks++) {
-                const int c = cc + 8 * g;
-                half8 bf[MT];
+        }
+    };
+    half8 Ab[PF][NT], Bb[PF][MT];
+    auto load_step = [&](half8 (&A)[NT], half8 (&B)[MT]) {
+        if (l_ks < a.ksteps) {
+            if constexpr (CIN16) {
+                // Cin == 16: one k-step of 32 spans TWO filter taps (lanes g<2: tap 2i, g>=2: tap 2i+1)
+                set_tap(2 * l_ks + (g >> 1));
+                const int c = 8 * (g & 1);
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
-                    bf[mt] = zero8;
-                    if (v[mt] && c < a.Cin) {
+                    B[mt] = zero8;
+                    if (pv[mt]) B[mt] = *reinterpret_cast<const half8 *>(p0[mt] + c);
+                }
+            } else {
+                const int c = l_cc + 8 * g;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    B[mt] = zero8;
+                    if (pv[mt] && c < a.Cin) {
                         const half_t *q = (c < a.s0.C) ? (p0[mt] + c) : (p1[mt] + (c - a.s0.C));
-                        bf[mt] = *reinterpret_cast<const half8 *>(q);
+                        B[mt] = *reinterpret_cast<const half8 *>(q);
                     }
                 }
-                half8 af[NT];
+            }
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) af[nt] = wp[(size_t)(nt * a.ksteps + ks) * 64];
+            for (int nt = 0; nt < NT; nt++) A[nt] = wp[(size_t)(nt * a.ksteps + l_ks) * 64];
+        }
+        // advance
+        l_ks++;
+        if constexpr (!CIN16) {
+            l_cc += 32;
+            if (l_cc >= a.Cin) {
+                l_cc = 0;
+                l_tap++;
+                set_tap(l_tap);
+            }
+        }
+    };
+
+    if constexpr (!CIN16) set_tap(0);
+#pragma unroll
+    for (int i = 0; i < PF; i++) load_step(Ab[i], Bb[i]);
+    for (int s = 0; s < a.ksteps; s += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            if (s + i < a.ksteps) {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab[i][nt], Bb[i][mt], acc[mt][nt], 0, 0, 0);
+                load_step(Ab[i], Bb[i]);
             }
         }
     }
 
     // ---- epilogue: bias, SiLU, shortcut, convert, NHWC store ----
-    // D layout of 16x16x32: col = lane & 15 (pixel), row = (lane >> 4) * 4 + reg (cout row of the tile)
+    // D layout of 16x16x32: col = lane & 15 (pixel), row = (lane >> 4) * 4 + reg (cout row of the tile).
+    // a.pair: the host packed the weight rows so that tiles (2u, 2u+1) interleave in groups of 4
+    // channels: lane g of tile t holds channels (t>>1)*32 + g*8 + (t&1)*4 + [0,4).
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
         if (!mv[mt]) continue;
         const size_t m = (size_t)mm[mt];
-        if constexpr (PAIR) {
+        if constexpr (!OUT_F32 && (NT % 2 == 0)) {
+            if (a.pair) {
 #pragma unroll
-            for (int u = 0; u < NT / 2; u++) {
-                const int c0 = (nt0 / 2 + u) * 32 + g * 8;
-                float vals[8];
+                for (int u = 0; u < NT / 2; u++) {
+                    const int c0 = (nt0 / 2 + u) * 32 + g * 8;
+                    float vals[8];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    vals[i] = acc[mt][2 * u][i] + a.bias[c0 + i];
-                    vals[4 + i] = acc[mt][2 * u + 1][i] + a.bias[c0 + 4 + i];
-                }
-                if (ACT == 1) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
-                }
-                if (a.res) {
-                    const half8 rv = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + c0);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) vals[i] += (float)rv[i];
-                }
-                half8 o;
-#pragma unroll
-                for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
-                *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = o;
-            }
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                const int c0 = (nt0 + nt) * 16 + g * 4;
-                float vals[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) vals[i] = acc[mt][nt][i] + a.bias[c0 + i];
-                if (ACT == 1) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
-                }
-                if constexpr (OUT_F32) {
-                    *reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + m * a.out_ld + c0) =
-                        (f32x4){vals[0], vals[1], vals[2], vals[3]};
-                } else {
-                    if (a.res) {
-                        const half4 rv = *reinterpret_cast<const half4 *>(a.res + m * a.res_ld + c0);
-#pragma unroll
-                        for (int i = 0; i < 4; i++) vals[i] += (float)rv[i];
+                    for (int i = 0; i < 4; i++) {
+                        vals[i] = acc[mt][2 * u][i] + a.bias[c0 + i];
+                        vals[4 + i] = acc[mt][2 * u + 1][i] + a.bias[c0 + 4 + i];
                     }
-                    *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) =
-                        (half4){(half_t)vals[0], (half_t)vals[1], (half_t)vals[2], (half_t)vals[3]};
+                    if (ACT == 1) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
+                    }
+                    if (a.res) {
+                        const half8 rv = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + c0);
+#pragma unroll
+                        for (int i = 0; i < 8; i++) vals[i] += (float)rv[i];
+                    }
+                    half8 o;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
+                    *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = o;
                 }
+                continue;
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const int t = nt0 + nt;
+            const int c0 = a.pair ? ((t >> 1) * 32 + g * 8 + (t & 1) * 4) : (t * 16 + g * 4);
+            float vals[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) vals[i] = acc[mt][nt][i] + a.bias[c0 + i];
+            if (ACT == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
+            }
+            if constexpr (OUT_F32) {
+                *reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + m * a.out_ld + c0) =
+                    (f32x4){vals[0], vals[1], vals[2], vals[3]};
+            } else {
+                if (a.res) {
+                    const half4 rv = *reinterpret_cast<const half4 *>(a.res + m * a.res_ld + c0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) vals[i] += (float)rv[i];
+                }
+                *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) =
+                    (half4){(half_t)vals[0], (half_t)vals[1], (half_t)vals[2], (half_t)vals[3]};
             }
         }
     }
@@ -182,37 +203,33 @@ static void launch_inst(const ConvArgs &a, hipStream_t s)
     hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MT, NT, CIN16, ACT, OUT_F32>), dim3(bx, by), dim3(256), 0, s, a);
 }
 
-template <int KS, int STRIDE, int NT, bool CIN16, int ACT, bool OUT_F32>
-static void launch_mt(int mt, const ConvArgs &a, hipStream_t s)
+template <int KS, int STRIDE, bool CIN16, int ACT, bool OUT_F32>
+static bool launch_tile(int mt, int nt, const ConvArgs &a, hipStream_t s)
 {
-    if (mt == 2) launch_inst<KS, STRIDE, 2, NT, CIN16, ACT, OUT_F32>(a, s);
-    else launch_inst<KS, STRIDE, 1, NT, CIN16, ACT, OUT_F32>(a, s);
+#define IRMV_TILE(MT_, NT_)                                                   \
+    if (mt == MT_ && nt == NT_) {                                             \
+        launch_inst<KS, STRIDE, MT_, NT_, CIN16, ACT, OUT_F32>(a, s);         \
+        return true;                                                          \
+    }
+    IRMV_TILE(1, 1) IRMV_TILE(2, 1) IRMV_TILE(4, 1)
+    IRMV_TILE(1, 2) IRMV_TILE(2, 2) IRMV_TILE(4, 2)
+    IRMV_TILE(1, 4) IRMV_TILE(2, 4) IRMV_TILE(4, 4)
+#undef IRMV_TILE
+    return false;
 }
 
 bool launch_conv(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
 {
-    if (c.mt != 1 && c.mt != 2) return false;
     if (a.cout_pad % (16 * c.nt) != 0) return false;
-#define IRMV_CASE(KS_, ST_, NT_, C16_, ACT_, F32_)                                                        \
-    if (c.ks == KS_ && c.stride == ST_ && c.nt == NT_ && c.cin16 == C16_ && c.act == ACT_ && c.out_f32 == F32_) { \
-        launch_mt<KS_, ST_, NT_, C16_, ACT_, F32_>(c.mt, a, s);                                           \
-        return true;                                                                                      \
-    }
-    // 3x3 stride 1, SiLU, fp16 out
-    IRMV_CASE(3, 1, 1, false, 1, false)
-    IRMV_CASE(3, 1, 1, true, 1, false)
-    IRMV_CASE(3, 1, 2, false, 1, false)
-    IRMV_CASE(3, 1, 4, false, 1, false)
-    // 3x3 stride 2
-    IRMV_CASE(3, 2, 2, true, 1, false)
-    IRMV_CASE(3, 2, 2, false, 1, false)
-    IRMV_CASE(3, 2, 4, false, 1, false)
-    // 1x1 SiLU
-    IRMV_CASE(1, 1, 2, false, 1, false)
-    IRMV_CASE(1, 1, 4, false, 1, false)
-    // 1x1 head finals: bias only, fp32 out
-    IRMV_CASE(1, 1, 1, false, 0, true)
-    IRMV_CASE(1, 1, 4, false, 0, true)
+#define IRMV_CASE(KS_, ST_, C16_, ACT_, F32_)                                                             \
+    if (c.ks == KS_ && c.stride == ST_ && c.cin16 == C16_ && c.act == ACT_ && c.out_f32 == F32_)          \
+        return launch_tile<KS_, ST_, C16_, ACT_, F32_>(c.mt, c.nt, a, s);
+    IRMV_CASE(3, 1, false, 1, false)   // 3x3 stride 1, SiLU, fp16 out
+    IRMV_CASE(3, 1, true, 1, false)
+    IRMV_CASE(3, 2, false, 1, false)   // 3x3 stride 2
+    IRMV_CASE(3, 2, true, 1, false)
+    IRMV_CASE(1, 1, false, 1, false)   // 1x1 SiLU
+    IRMV_CASE(1, 1, false, 0, true)    // 1x1 head finals: bias only, fp32 out
 #undef IRMV_CASE
     return false;
 }
@@ -226,8 +243,97 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 
 // SPPF (SURVEY.md Appendix A "Blocks"): p1 = maxpool5(a), p2 = maxpool5(p1),
 // p3 = maxpool5(p2).  Stride-1 max pools compose, so p2 / p3 are the clipped 9x9 /
-// 13x13 window maxima of `a`: one kernel, one read of the 13x13 neighbourhood,
-// three nested maxima.  One lane per (pixel, 8-channel chunk).
+// 13x13 window maxima of `a`, and every window maximum is separable.
+//
+// LDS version: one workgroup per (frame, CW-channel slab).  The slab [H*W][CW] is
+// staged once; pass 1 writes the three horizontal maxima (radius 2, 4, 6) to LDS,
+// pass 2 takes the vertical maxima of those: 13 + 27 LDS reads per (pixel, 8
+// channels) instead of 169 global loads.  Max is exact, so this is bit-identical
+// to the chained pools.
+__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(half_t *buf, int H, int W, int C, int CW)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int HW = H * W, chunks = CW >> 3;
+    half8 *sa = reinterpret_cast<half8 *>(smem);          // [HW][chunks]
+    half8 *s2 = sa + (size_t)HW * chunks;                 // horizontal max, radius 2
+    half8 *s4 = s2 + (size_t)HW * chunks;
+    half8 *s6 = s4 + (size_t)HW * chunks;
+    const int slabs = C / CW;
+    const int b = blockIdx.x / slabs, slab = blockIdx.x - b * slabs;
+    const int ld = 4 * C;
+    half_t *base = buf + (size_t)b * HW * ld + slab * CW;
+    const int items = HW * chunks;
+    for (int t = threadIdx.x; t < items; t += blockDim.x) {
+        const int p = t / chunks, ch = t - p * chunks;
+        sa[t] = *reinterpret_cast<const half8 *>(base + (size_t)p * ld + ch * 8);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < items; t += blockDim.x) {
+        const int p = t / chunks, ch = t - p * chunks;
+        const int y = p / W, x = p - y * W;
+        half8 m2 = sa[t], m4, m6;
+#pragma unroll
+        for (int d = 1; d <= 2; d++) {
+            if (x - d >= 0) { const half8 v = sa[(p - d) * chunks + ch];
+#pragma unroll
+                for (int i = 0; i < 8; i++) m2[i] = v[i] > m2[i] ? v[i] : m2[i]; }
+            if (x + d < W) { const half8 v = sa[(p + d) * chunks + ch];
+#pragma unroll
+                for (int i = 0; i < 8; i++) m2[i] = v[i] > m2[i] ? v[i] : m2[i]; }
+        }
+        m4 = m2;
+#pragma unroll
+        for (int d = 3; d <= 4; d++) {
+            if (x - d >= 0) { const half8 v = sa[(p - d) * chunks + ch];
+#pragma unroll
+                for (int i = 0; i < 8; i++) m4[i] = v[i] > m4[i] ? v[i] : m4[i]; }
+            if (x + d < W) { const half8 v = sa[(p + d) * chunks + ch];
+#pragma unroll
+                for (int i = 0; i < 8; i++) m4[i] = v[i] > m4[i] ? v[i] : m4[i]; }
+        }
+        m6 = m4;
+#pragma unroll
+        for (int d = 5; d <= 6; d++) {
+            if (x - d >= 0) { const half8 v = sa[(p - d) * chunks + ch];
+#pragma unroll
+                for (int i = 0; i < 8; i++) m6[i] = v[i] > m6[i] ? v[i] : m6[i]; }
+            if (x + d < W) { const half8 v = sa[(p + d) * chunks + ch];
+#pragma unroll
+                for (int i = 0; i < 8; i++) m6[i] = v[i] > m6[i] ? v[i] : m6[i]; }
+        }
+        s2[t] = m2; s4[t] = m4; s6[t] = m6;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < items; t += blockDim.x) {
+        const int p = t / chunks, ch = t - p * chunks;
+        const int y = p / W;
+        half8 m5 = s2[t], m9 = s4[t], m13 = s6[t];
+        for (int d = 1; d <= 6; d++) {
+#pragma unroll
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+                const int yy = y + sgn * d;
+                if (yy < 0 || yy >= H) continue;
+                const int q = (p + sgn * d * W) * chunks + ch;
+                const half8 v6 = s6[q];
+#pragma unroll
+                for (int i = 0; i < 8; i++) m13[i] = v6[i] > m13[i] ? v6[i] : m13[i];
+                if (d <= 4) { const half8 v4 = s4[q];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) m9[i] = v4[i] > m9[i] ? v4[i] : m9[i]; }
+                if (d <= 2) { const half8 v2 = s2[q];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) m5[i] = v2[i] > m5[i] ? v2[i] : m5[i]; }
+            }
+        }
+        half_t *o = base + (size_t)p * ld + ch * 8;
+        *reinterpret_cast<half8 *>(o + C) = m5;
+        *reinterpret_cast<half8 *>(o + 2 * C) = m9;
+        *reinterpret_cast<half8 *>(o + 3 * C) = m13;
+    }
+}
+
+// Global-memory version for feature maps too large for the LDS slab: one lane per
+// (pixel, 8-channel chunk), three nested maxima over the 13x13 neighbourhood.
 __global__ __launch_bounds__(256) void sppf_pool_kernel(half_t *buf, int batch, int H, int W, int C)
 {
     const int chunks = C >> 3;
@@ -268,6 +374,20 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(half_t *buf, int batch, 
 
 void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s)
 {
+    // widest channel slab whose four [H*W][CW] fp16 images fit in LDS
+    int cw = 0;
+    for (int c = 32; c >= 8; c >>= 1)
+        if (C % c == 0 && (size_t)4 * H * W * c * 2 <= 150 * 1024) { cw = c; break; }
+    if (cw) {
+        const size_t lds = (size_t)4 * H * W * cw * 2;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sppf_pool_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(sppf_pool_lds_kernel, dim3(batch * (C / cw)), dim3(256), lds, s, buf, H, W, C, cw);
+        return;
+    }
     const int total = batch * H * W * (C >> 3);
     hipLaunchKernelGGL(sppf_pool_kernel, dim3((total + 255) / 256), dim3(256), 0, s, buf, batch, H, W, C);
 }

@@ -47,12 +47,14 @@ __device__ __forceinline__ float unorderable(uint32_t u)
     return __uint_as_float(u);
 }
 
-__device__ __forceinline__ void anchor_geom(int a, int net, int &ix, int &iy, int &stride, int &lvl, int &rin)
+// anchor -> grid position, stride, and the (level base, level size, index in level) that locate its head record
+__device__ __forceinline__ void anchor_geom(int a, int net, int &ix, int &iy, int &stride, int &lbase, int &lhw, int &rin)
 {
     int base = 0;
     ix = iy = 0;
     stride = 0;
-    lvl = 0;
+    lbase = 0;
+    lhw = 1;
     rin = 0;
 #pragma unroll
     for (int l = 0; l < 3; l++) {
@@ -62,18 +64,17 @@ __device__ __forceinline__ void anchor_geom(int a, int net, int &ix, int &iy, in
             iy = r / w;
             ix = r - iy * w;
             stride = s;
-            lvl = l;
+            lbase = base;
+            lhw = cnt;
             rin = r;
         }
         base += cnt;
     }
 }
 
-__device__ __forceinline__ const float *head_rec(const PostArgs &a, int b, int lvl, int rin)
+__device__ __forceinline__ const float *head_rec(const float *head_all, int slots_total, int slot, int lbase, int lhw, int rin)
 {
-    const float *h = lvl == 0 ? a.head[0] : (lvl == 1 ? a.head[1] : a.head[2]);
-    const int hw = lvl == 0 ? a.lvl_hw[0] : (lvl == 1 ? a.lvl_hw[1] : a.lvl_hw[2]);
-    return h + ((size_t)b * hw + rin) * kHeadRec;
+    return head_all + ((size_t)lbase * slots_total + (size_t)slot * lhw + rin) * kHeadRec;
 }
 
 __device__ __forceinline__ float dfl_side(const float *l)
@@ -91,32 +92,44 @@ __device__ __forceinline__ float dfl_side(const float *l)
     return sj / se;
 }
 
-// One lane per (frame, anchor): box -> boxes[], passing (anchor, class) pairs -> keys[]
+// Four lanes per (frame, anchor): lane q owns box side q (16 DFL logits, one 64-byte
+// read) and classes 4q..4q+3, so a wave reads 16 whole 320-byte head records and
+// nothing lives in scratch.  The per-side arithmetic is exactly dfl_side().
 __global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= batch * a.A) return;
-    const int b = t / a.A, an = t - b * a.A;
-    int ix, iy, s, lvl, rin;
-    anchor_geom(an, a.net, ix, iy, s, lvl, rin);
-    const float *rec = head_rec(a, b, lvl, rin);
-    float l[64];
+    const int quad = t >> 2, q = t & 3;
+    const bool live = quad < batch * a.A;
+    const int qa = live ? quad : 0;
+    const int b = qa / a.A, an = qa - b * a.A;
+    int ix, iy, s, lbase, lhw, rin;
+    anchor_geom(an, a.net, ix, iy, s, lbase, lhw, rin);
+    const float *rec = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
+    float l[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(rec)[i];
+    for (int i = 0; i < 4; i++) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(rec + 16 * q)[i];
         l[4 * i] = v[0]; l[4 * i + 1] = v[1]; l[4 * i + 2] = v[2]; l[4 * i + 3] = v[3];
     }
-    const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)s;
-    const float dl = dfl_side(l), dt = dfl_side(l + 16), dr = dfl_side(l + 32), db = dfl_side(l + 48);
-    f32x4 box;
-    box[0] = (ax - dl) * sf;
-    box[1] = (ay - dt) * sf;
-    box[2] = (ax + dr) * sf;
-    box[3] = (ay + db) * sf;
-    reinterpret_cast<f32x4 *>(a.boxes)[t] = box;
-    for (int c = 0; c < a.nc; c++) {
-        const float logit = rec[kClsOff + c];
-        if (logit > a.logit_thr) {
+    const float d = dfl_side(l);
+    const int lane = threadIdx.x & 63, base = lane & ~3;
+    const float dl = __shfl(d, base), dt = __shfl(d, base + 1), dr = __shfl(d, base + 2), db = __shfl(d, base + 3);
+    if (!live) return;
+    if (q == 0) {
+        const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)s;
+        f32x4 box;
+        box[0] = (ax - dl) * sf;
+        box[1] = (ay - dt) * sf;
+        box[2] = (ax + dr) * sf;
+        box[3] = (ay + db) * sf;
+        reinterpret_cast<f32x4 *>(a.boxes)[quad] = box;
+    }
+    const f32x4 cl = reinterpret_cast<const f32x4 *>(rec + kClsOff)[q];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = 4 * q + i;
+        const float logit = cl[i];
+        if (c < a.nc && logit > a.logit_thr) {
             const int idx = atomicAdd(&a.counts[b], 1);
             if (idx < kCandCap)
                 a.keys[(size_t)b * kCandCap + idx] =
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
 
 void launch_decode(const PostArgs &a, int batch, hipStream_t s)
 {
-    const int total = batch * a.A;
+    const int total = batch * a.A * 4;
     hipLaunchKernelGGL(decode_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a, batch);
 }
 
@@ -347,70 +360,137 @@ void launch_pnp_only(const PnpConst &c, const float *pts, int n, int armor_size,
 }
 
 // ---------------------------------------------------------------------------
-// One workgroup (1024 lanes) per frame: bitonic sort of the candidate keys in
-// LDS, blocked greedy NMS on wave 0, then one lane per survivor for keypoints,
-// output scaling and PnP.
+// One workgroup (1024 lanes = 16 waves) per frame:
+//   1. sort the candidate keys in LDS (rank sort up to 2048 keys: one pass, no
+//      barrier ladder; bitonic above that);
+//   2. all 16 waves, one 64-candidate block each: the block's 64x64 same-class
+//      IoU > thr relation as one 64-bit "who suppresses me" mask per candidate
+//      (independent of the kept set, so it is computed up front, in parallel);
+//   3. wave 0 walks the blocks in score order: test against the kept boxes OF THE
+//      CANDIDATE'S CLASS (per-class kept lists), resolve the block with ballots,
+//      append survivors;
+//   4. one lane per survivor: keypoints, parse_output scaling, fp64 IPPE PnP.
+// The greedy walk is exactly the oracle's: same comparisons, same order.
 // ---------------------------------------------------------------------------
+constexpr int kRankSortMax = 2048;
+constexpr int kSupCap = 4096;   // candidates whose intra-block masks are precomputed
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// "who of the 64 candidates of my block suppresses me": bit j set iff j < lane, same class, IoU > thr.
+// sbox / scls: this wave's private LDS staging of the block.
+__device__ __forceinline__ unsigned long long block_sup_mask(f32x4 box, int cls, int lane, float iou_thr, f32x4 *sbox, int *scls)
+{
+    sbox[lane] = box;
+    scls[lane] = cls;
+    wave_lds_sync();
+    unsigned long long sup = 0ull;
+    for (int j = 0; j < 64; j++) {
+        const f32x4 bj = sbox[j];
+        const int cj = scls[j];
+        if (j < lane && cj == cls && cls >= 0 && iou_xyxy(bj, box) > iou_thr) sup |= 1ull << j;
+    }
+    wave_lds_sync();
+    return sup;
+}
+
 __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
 {
-    __shared__ unsigned long long skeys[kCandCap];          // 64 KiB
+    __shared__ unsigned long long skeys[kCandCap];          // 64 KiB: candidate keys (bitonic sorts in place)
+    __shared__ unsigned long long srank[kRankSortMax];      // 16 KiB: rank-sort destination
+    __shared__ unsigned long long ssup[kSupCap];            // 32 KiB: intra-block suppression masks
+    __shared__ f32x4 stage_box[16][64];                     // 16 KiB: per-wave block staging
+    __shared__ int stage_cls[16][64];
     __shared__ f32x4 kept_box[kMaxDetCap];
     __shared__ int kept_cls[kMaxDetCap];
     __shared__ unsigned long long kept_key[kMaxDetCap];
+    __shared__ unsigned short cls_list[16][kMaxDetCap];     // per class: indices into kept_*
+    __shared__ int cls_cnt[16];
     __shared__ int s_kept;
 
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_total = a.counts[b];
     const int n_stored = n_total < kCandCap ? n_total : kCandCap;
-    int npow = 64;
-    while (npow < n_stored) npow <<= 1;
     const unsigned long long *gk = a.keys + (size_t)b * kCandCap;
-    for (int i = tid; i < npow; i += blockDim.x) skeys[i] = i < n_stored ? gk[i] : 0ull;
-    __syncthreads();
-    // bitonic sort, descending
-    for (int k = 2; k <= npow; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow; i += blockDim.x) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long x = skeys[i], y = skeys[l];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (x < y) : (x > y)) { skeys[i] = y; skeys[l] = x; }
-                }
-            }
-            __syncthreads();
+    const unsigned long long *sorted;
+    if (tid < 16) cls_cnt[tid] = 0;
+
+    if (n_stored <= kRankSortMax) {
+        for (int i = tid; i < n_stored; i += blockDim.x) skeys[i] = gk[i];
+        __syncthreads();
+        // keys are unique, so "number of keys greater than mine" is a permutation
+        for (int i = tid; i < n_stored; i += blockDim.x) {
+            const unsigned long long mine = skeys[i];
+            int rank = 0;
+            for (int j = 0; j < n_stored; j++) rank += skeys[j] > mine ? 1 : 0;
+            srank[rank] = mine;
         }
+        __syncthreads();
+        sorted = srank;
+    } else {
+        int npow = kRankSortMax * 2;
+        while (npow < n_stored) npow <<= 1;
+        for (int i = tid; i < npow; i += blockDim.x) skeys[i] = i < n_stored ? gk[i] : 0ull;
+        __syncthreads();
+        for (int k = 2; k <= npow; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < npow; i += blockDim.x) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long x = skeys[i], y = skeys[l];
+                        const bool desc = (i & k) == 0;
+                        if (desc ? (x < y) : (x > y)) { skeys[i] = y; skeys[l] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        sorted = skeys;
     }
     const int n = n_stored < a.pre_nms_cap ? n_stored : a.pre_nms_cap;
+    const f32x4 *boxes = reinterpret_cast<const f32x4 *>(a.boxes) + (size_t)b * a.A;
 
-    if (tid < 64) {
-        const int lane = tid;
+    // ---- 2. intra-block masks, one block per wave ----
+    const int n_pre = n < kSupCap ? n : kSupCap;
+    for (int start = wave * 64; start < n_pre; start += 16 * 64) {
+        const int idx = start + lane;
+        const bool valid = idx < n;
+        const unsigned long long key = valid ? sorted[idx] : 0ull;
+        const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
+        const int an = valid ? (int)(id / (uint32_t)a.nc) : 0;
+        const int cls = valid ? (int)(id % (uint32_t)a.nc) : -1;
+        const f32x4 box = valid ? boxes[an] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        ssup[idx] = block_sup_mask(box, cls, lane, a.iou_thr, stage_box[wave], stage_cls[wave]);
+    }
+    __syncthreads();
+
+    // ---- 3. greedy walk on wave 0 ----
+    if (wave == 0) {
         int kept = 0;
-        const f32x4 *boxes = reinterpret_cast<const f32x4 *>(a.boxes) + (size_t)b * a.A;
         for (int start = 0; start < n && kept < a.max_det; start += 64) {
             const int idx = start + lane;
             const bool valid = idx < n;
-            const unsigned long long key = valid ? skeys[idx] : 0ull;
+            const unsigned long long key = valid ? sorted[idx] : 0ull;
             const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
             const int an = valid ? (int)(id / (uint32_t)a.nc) : 0;
             const int cls = valid ? (int)(id % (uint32_t)a.nc) : -1;
             const f32x4 box = valid ? boxes[an] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            // phase A: against everything kept so far
+            // against the kept boxes of my class
             bool alive = valid;
-            for (int j = 0; j < kept; j++) {
-                if (kept_cls[j] == cls && iou_xyxy(kept_box[j], box) > a.iou_thr) alive = false;
+            const int mycnt = valid ? cls_cnt[cls] : 0;
+            for (int j = 0; __any(j < mycnt); j++) {
+                if (j < mycnt) {
+                    const int k = cls_list[cls][j];
+                    if (iou_xyxy(kept_box[k], box) > a.iou_thr) alive = false;
+                }
             }
-            // phase B: who inside this block of 64 suppresses me (only earlier lanes can)
-            unsigned long long sup = 0ull;
-            for (int j = 0; j < 64; j++) {
-                f32x4 bj;
-                bj[0] = __shfl(box[0], j);
-                bj[1] = __shfl(box[1], j);
-                bj[2] = __shfl(box[2], j);
-                bj[3] = __shfl(box[3], j);
-                const int cj = __shfl(cls, j);
-                if (j < lane && cj == cls && cls >= 0 && iou_xyxy(bj, box) > a.iou_thr) sup |= 1ull << j;
-            }
+            const unsigned long long sup = start < n_pre ? ssup[idx]
+                                                        : block_sup_mask(box, cls, lane, a.iou_thr, stage_box[0], stage_cls[0]);
             // sequential resolve, earliest first
             unsigned long long A = __ballot(alive);
             int taken = 0;
@@ -425,12 +505,20 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
                     A &= ~col;
                 }
             }
-            if ((A >> lane) & 1ull) {
-                const int pos = kept + __popcll(A & ((1ull << lane) - 1ull));
+            const bool mine = (A >> lane) & 1ull;
+            const int pos = kept + __popcll(A & ((1ull << lane) - 1ull));
+            if (mine) {
                 kept_box[pos] = box;
                 kept_cls[pos] = cls;
                 kept_key[pos] = key;
             }
+            for (int c = 0; c < a.nc; c++) {
+                const unsigned long long mc = __ballot(mine && cls == c);
+                if (mine && cls == c) cls_list[c][cls_cnt[c] + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)pos;
+                wave_lds_sync();
+                if (lane == 0 && mc) cls_cnt[c] += __popcll(mc);
+            }
+            wave_lds_sync();
             kept += __popcll(A);
         }
         if (lane == 0) s_kept = kept;
@@ -445,10 +533,10 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         fo.pad = 0;
         a.fout[b] = fo;
     }
-    // one lane per survivor (spread over waves: lane j*8 of the block keeps fp64 PnP off a single SIMD)
-    if (tid < a.max_det) {
+    // ---- 4. one lane per survivor, spread over the waves (tid = j * 4) so the fp64 PnP lanes do not share a SIMD ----
+    const int j = tid >> 2;
+    if ((tid & 3) == 0 && j < a.max_det) {
         DevDet d;
-        const int j = tid;
         if (j < kept) {
             const f32x4 box = kept_box[j];
             const unsigned long long key = kept_key[j];
@@ -458,10 +546,10 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             d.score = 1.0f / (1.0f + irmv_expf(-logit));
             d.cls = kept_cls[j];
             d.anchor = an;
-            int ix, iy, s, lvl, rin;
-            anchor_geom(an, a.net, ix, iy, s, lvl, rin);
+            int ix, iy, s, lbase, lhw, rin;
+            anchor_geom(an, a.net, ix, iy, s, lbase, lhw, rin);
             const float axm = ((float)ix + 0.5f) - 0.5f, aym = ((float)iy + 0.5f) - 0.5f, sf = (float)s;
-            const float *kp = head_rec(a, b, lvl, rin) + kKptOff;
+            const float *kp = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin) + kKptOff;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 d.box_net[i] = box[i];
@@ -483,7 +571,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             for (int i = 0; i < 3; i++) { d.rvec[i] = 0.0; d.tvec[i] = 0.0; }
             d.quat[0] = d.quat[1] = d.quat[2] = 0.0; d.quat[3] = 1.0;
             d.pnp_ok = 0;
-            if (a.nk >= 8) d.pnp_ok = solve_pnp_ippe(a.pnp, d.kpts, a.armor_size, d.rvec, d.tvec, d.quat) ? 1 : 0;
+            if (a.nk >= 8) d.pnp_ok = solve_pnp_ippe(*a.pnp, d.kpts, a.armor_size, d.rvec, d.tvec, d.quat) ? 1 : 0;
         } else {
             // EfficientNMS zero-pads its outputs
             unsigned char *z = reinterpret_cast<unsigned char *>(&d);

@@ -91,55 +91,64 @@ void launch_rotate180(const uint8_t *src, uint8_t *dst, int sw, int sh, hipStrea
     hipLaunchKernelGGL(rotate180_kernel, dim3(2048), dim3(256), 0, s, src, dst, sw, sh);
 }
 
-// model.0.conv (3x3 stride 2, 3 -> 16, SiLU).  K = 27 is too thin for MFMA
-// (SURVEY.md section 7 item 4): one lane per output pixel, the 432 weights are
-// wave-uniform and ride in SGPRs.
+// model.0.conv (3x3 stride 2, 3 -> 16, SiLU) on the matrix cores.
+// The input is NHWC4 (rgb0), so with K laid out as [kernel row kh][4 tap slots][4
+// channels] (16 k per row, the 4th slot and the 4th channel carry zero weights) the
+// 8 k-values of an MFMA lane are two horizontally adjacent input pixels = 16
+// contiguous bytes.  K = 48 -> two v_mfma_f32_16x16x32_f16 per 16 pixels x 16
+// channels; the kernel is bound by its 6.6 MB/frame of HBM traffic, not by math.
 __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a)
 {
-    const int Ho = a.net >> 1;
-    const int total = a.batch * Ho * Ho;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total) return;
-    const int b = p / (Ho * Ho), rem = p - b * Ho * Ho, oy = rem / Ho, ox = rem - oy * Ho;
-    float acc[16];
+    constexpr int MT = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int Ho = a.net >> 1, HWo = Ho * Ho;
+    const int M = a.batch * HWo;
+    const int tile0 = (blockIdx.x * 4 + wave) * MT;
+    const half8 *wp = reinterpret_cast<const half8 *>(a.w) + lane;
+    const half8 w0 = wp[0], w1 = wp[64];
+    const half4 z4 = (half4){0, 0, 0, 0};
 #pragma unroll
-    for (int o = 0; o < 16; o++) acc[o] = a.b[o];
-    const half_t *xb = a.x + (size_t)b * a.net * a.net * 4;
+    for (int mt = 0; mt < MT; mt++) {
+        const int m = (tile0 + mt) * 16 + r;
+        const bool mv = m < M;
+        const int mm = mv ? m : 0;
+        const int b = mm / HWo, rem = mm - b * HWo, oy = rem / Ho, ox = rem - oy * Ho;
+        const half_t *xb = a.x + (size_t)b * a.net * a.net * 4;
+        const int ix0 = ox * 2 - 1 + 2 * (g & 1);       // first pixel of this lane's tap pair
+        half8 bf[2];
 #pragma unroll
-    for (int kh = 0; kh < 3; kh++) {
-        const int iy = oy * 2 - 1 + kh;
-#pragma unroll
-        for (int kw = 0; kw < 3; kw++) {
-            const int ix = ox * 2 - 1 + kw;
-            half4 xv = (half4){0, 0, 0, 0};
-            if ((unsigned)iy < (unsigned)a.net && (unsigned)ix < (unsigned)a.net)
-                xv = *reinterpret_cast<const half4 *>(xb + ((size_t)iy * a.net + ix) * 4);
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float xf = (float)xv[c];
-                const float *w = a.w + ((kh * 3 + kw) * 3 + c) * 16;
-#pragma unroll
-                for (int o = 0; o < 16; o++) acc[o] = fmaf(xf, w[o], acc[o]);
+        for (int s = 0; s < 2; s++) {
+            const int kh = 2 * s + (g >> 1);
+            const int iy = oy * 2 - 1 + kh;
+            half4 lo = z4, hi = z4;
+            if (mv && kh < 3 && (unsigned)iy < (unsigned)a.net) {
+                const half_t *row = xb + (size_t)iy * a.net * 4;
+                if ((unsigned)ix0 < (unsigned)a.net) lo = *reinterpret_cast<const half4 *>(row + (size_t)ix0 * 4);
+                if ((g & 1) == 0) hi = *reinterpret_cast<const half4 *>(row + (size_t)(ix0 + 1) * 4);   // kw = 1; slot 3 is padding
             }
+            bf[s] = (half8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, bf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, bf[1], acc, 0, 0, 0);
+        if (mv) {
+            half4 o;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float v = acc[i] + a.b[g * 4 + i];
+                o[i] = (half_t)(v * __frcp_rn(1.0f + __expf(-v)));
+            }
+            *reinterpret_cast<half4 *>(a.y + (size_t)mm * 16 + g * 4) = o;
         }
     }
-    half8 o0, o1;
-#pragma unroll
-    for (int o = 0; o < 8; o++) {
-        const float v0 = acc[o], v1 = acc[o + 8];
-        o0[o] = (half_t)(v0 * __frcp_rn(1.0f + __expf(-v0)));
-        o1[o] = (half_t)(v1 * __frcp_rn(1.0f + __expf(-v1)));
-    }
-    half_t *y = a.y + (size_t)p * 16;
-    *reinterpret_cast<half8 *>(y) = o0;
-    *reinterpret_cast<half8 *>(y + 8) = o1;
 }
 
 void launch_conv0(const Conv0Args &a, hipStream_t s)
 {
     const int Ho = a.net >> 1;
-    const int total = a.batch * Ho * Ho;
-    hipLaunchKernelGGL(conv0_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+    const int tiles = (a.batch * Ho * Ho + 15) / 16;
+    hipLaunchKernelGGL(conv0_kernel, dim3((tiles + 15) / 16), dim3(256), 0, s, a);
 }
 
 }  // namespace irmv

@@ -319,3 +319,20 @@ def test_pnp_batch_random_quads_vs_oracle():
         if o["ok"] and abs(o["err"][0] - o["err"][1]) > 1e-7:
             assert np.abs(r[i] - o["rvec"]).max() <= 1e-6 and np.abs(t[i] - o["tvec"]).max() <= 1e-6
     solver.close()
+
+
+def test_tile_choice_is_bitwise_neutral(blob, frame0):
+    """The autotuner may pick different (MT, NT) tiles for different batch sizes; every tile walks K in
+    the same order, so heads must agree bit for bit between a 1-slot and a 4-slot engine."""
+    heads = []
+    for S in (1, 4):
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=S) as e:
+            for s in range(S):
+                e.get_src_image_buffer(s)[:] = frame0
+            e.submit(0, S)
+            e.wait()
+            heads.append(e.read_head(S - 1).copy())
+            if S > 1:
+                e.detect(0)                       # single-frame step on the batched engine: its own tile set
+                heads.append(e.read_head(0).copy())
+    assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2])
