@@ -110,6 +110,7 @@ struct Op {
     int Hin = 0, Win = 0, Hout = 0, Wout = 0, cin = 0, cout = 0, cout_pad = 0, ksteps = 0;
     int out_t = -1, out_coff = 0, res_t = -1, res_coff = 0;
     half_t *w_packed = nullptr;
+    half_t *w_lds[3] = {nullptr, nullptr, nullptr};   // LDS-kernel layout for nt = 1 / 2 / 4 (eligible 3x3 layers only)
     float *bias = nullptr;
     double flops = 0, bytes = 0;  // per frame
     bool pair = false;
@@ -239,6 +240,31 @@ static int pack_conv(irmv_engine *e, const LayerW &l, Op &op)
     if (rc) return rc;
     HIP_TRY(hipMemcpy(op.w_packed, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(op.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    // LDS-kernel layout: [n-block][chunk of 32 ch][tap][tile in block][lane][8]
+    if (l.k == 3 && l.cin % 32 == 0 && l.act == 1 && !op.cfg.out_f32) {
+        const int chunks = l.cin / 32;
+        for (int v = 0; v < 3; v++) {
+            const int nt = 1 << v;
+            if (ntiles % nt != 0 || (nt > 1 && !pair)) continue;
+            std::vector<uint16_t> pl((size_t)ntiles * chunks * 9 * 512, 0);
+            for (int t = 0; t < ntiles; t++)
+                for (int ch = 0; ch < chunks; ch++)
+                    for (int tap = 0; tap < 9; tap++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            const int g = lane >> 4, r = lane & 15;
+                            const int co = tile_row_cout(t, r, pair);
+                            const int nb = t / nt, ti = t % nt;
+                            const size_t base = ((((size_t)nb * chunks + ch) * 9 + tap) * nt + ti) * 512 + (size_t)lane * 8;
+                            for (int j = 0; j < 8; j++) {
+                                const int c = ch * 32 + 8 * g + j;
+                                if (co < l.cout) pl[base + j] = l.w[((size_t)co * 9 + tap) * l.cin + c];
+                            }
+                        }
+            int rc2 = dev_alloc(e, (void **)&op.w_lds[v], pl.size() * 2);
+            if (rc2) return rc2;
+            HIP_TRY(hipMemcpy(op.w_lds[v], pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
+        }
+    }
     return IRMV_OK;
 }
 
@@ -262,6 +288,7 @@ static int add_conv(irmv_engine *e, const std::string &layer, SegRef s0, SegRef 
     if (out_coff + cout_pad > ot.C) return fail(IRMV_ERR_MODEL, "layer " + layer + ": output slice out of range");
     op.cfg.ks = l->k; op.cfg.stride = l->stride; op.cfg.act = l->act; op.cfg.out_f32 = ot.f32;
     op.cfg.cin16 = (l->cin == 16 && l->k == 3);
+    op.cfg.lds = false;
     const int nt_all = cout_pad / 16;
     op.cfg.nt = nt_all >= 4 ? 4 : nt_all;
     // enough workgroups to cover 256 CUs a few times, else halve the pixel tile
@@ -462,8 +489,8 @@ static int build_engine(irmv_engine *e)
     // ---- post-processing buffers ----
     TRY(dev_alloc(e, (void **)&e->boxes, (size_t)S * e->A * 16));
     TRY(dev_alloc(e, (void **)&e->keys, (size_t)S * kCandCap * 8));
-    TRY(dev_alloc(e, (void **)&e->counts, (size_t)S * 4));
-    HIP_TRY(hipMemset(e->counts, 0, (size_t)S * 4));
+    TRY(dev_alloc(e, (void **)&e->counts, (size_t)S * kCountStride * 4));
+    HIP_TRY(hipMemset(e->counts, 0, (size_t)S * kCountStride * 4));
     TRY(dev_alloc(e, (void **)&e->dets_dev, (size_t)S * c.max_det * sizeof(DevDet)));
     TRY(dev_alloc(e, (void **)&e->fout_dev, (size_t)S * sizeof(DevFrameOut)));
     HIP_TRY(hipMemset(e->dets_dev, 0, (size_t)S * c.max_det * sizeof(DevDet)));
@@ -632,6 +659,23 @@ extern "C" void *irmv_engine_src_device_buffer(irmv_engine *e, int slot)
     return e->src_dev + (size_t)slot * e->frame_bytes;
 }
 
+// tile choices already measured in this process, keyed by layer shape and batch (engines are created
+// repeatedly in tests and by multi-slot nodes; the kernels and the device do not change in between)
+static std::map<std::string, ConvCfg> g_tune_cache;
+
+static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int count, hipStream_t s)
+{
+    const int li = c.nt == 4 ? 2 : (c.nt == 2 ? 1 : 0);
+    if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, a, op.w_lds[li], count, s);
+    return launch_conv(c, a, s);
+}
+
+static void cfg_name(const ConvCfg &c, char *buf, int n)
+{
+    if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d", c.stride, c.mt, c.nt);
+    else conv_cfg_name(c, buf, n);
+}
+
 // ---- per-layer tile autotuner ---------------------------------------------------
 // Every conv layer is timed at its real shape with each (MT, NT) tile the kernel
 // family offers and keeps the fastest, once for full batched steps and once for
@@ -647,6 +691,9 @@ static int autotune_convs(irmv_engine *e)
     HIP_TRY(hipEventCreate(&ea));
     HIP_TRY(hipEventCreate(&eb));
     const int counts[2] = {e->cfg.num_slots, 1};
+    const bool verbose = getenv("IRMV_AUTOTUNE_VERBOSE") != nullptr;
+    const char *fam_env = getenv("IRMV_CONV_FAMILY");
+    const bool only_direct = fam_env && !strcmp(fam_env, "direct");
     for (Op &op : e->ops) {
         if (op.kind != OP_CONV) continue;
         for (int pass = 0; pass < (e->cfg.num_slots > 1 ? 2 : 1); pass++) {
@@ -654,25 +701,56 @@ static int autotune_convs(irmv_engine *e)
             fill_conv_args(e, op, 0, counts[pass], a);
             float best = 1e30f;
             ConvCfg best_cfg = pass == 0 ? op.cfg : op.cfg_one;
-            for (int mt = 1; mt <= 4; mt *= 2)
-                for (int nt = 1; nt <= 4; nt *= 2) {
-                    if (op.cout_pad % (16 * nt) != 0) continue;
-                    ConvCfg c = op.cfg;
-                    c.mt = mt; c.nt = nt;
-                    bool ok = true;
-                    for (int i = 0; i < 2 && ok; i++) ok = launch_conv(c, a, e->stream);
-                    if (!ok) continue;
-                    HIP_TRY(hipEventRecord(ea, e->stream));
-                    for (int i = 0; i < 6; i++) launch_conv(c, a, e->stream);
-                    HIP_TRY(hipEventRecord(eb, e->stream));
-                    HIP_TRY(hipEventSynchronize(eb));
-                    float ms = 0.f;
-                    HIP_TRY(hipEventElapsedTime(&ms, ea, eb));
-                    if (ms < best) { best = ms; best_cfg = c; }
-                }
-            if (pass == 0) { op.cfg = best_cfg; conv_cfg_name(op.cfg, op.kname, sizeof op.kname); }
-            else { op.cfg_one = best_cfg; conv_cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
-            if (e->cfg.num_slots == 1) { op.cfg_one = op.cfg; conv_cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
+            // Kernel family by a rule that does not depend on the batch (the two families walk K in
+            // different orders): LDS-staged whenever some tile of it fits this layer, else direct.
+            bool lds_ok = false;
+            if (!only_direct && op.cfg.ks == 3 && op.cfg.act == 1 && !op.cfg.out_f32)
+                for (int mt = 1; mt <= 4 && !lds_ok; mt *= 2)
+                    for (int nt = 1; nt <= 4 && !lds_ok; nt *= 2) {
+                        int pr = 0;
+                        const int li = nt == 4 ? 2 : (nt == 2 ? 1 : 0);
+                        lds_ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, mt, nt, &pr) > 0;
+                    }
+            char key[160];
+            snprintf(key, sizeof key, "%d|%d.%d.%d.%d.%d.%d|%dx%d>%dx%d|c%d.%d.%d.%d>%d|ld%d.%d.%d|n%d|%d", e->cfg.device, op.cfg.ks, op.cfg.stride,
+                     (int)op.cfg.cin16, op.cfg.act, (int)op.cfg.out_f32, (int)lds_ok, a.Hin, a.Win, a.Hout, a.Wout, a.s0.C, a.s1.C, a.s0.shift,
+                     a.s1.shift, a.cout_pad, a.s0.ld, a.s1.ld, a.out_ld, counts[pass], a.res ? 1 : 0);
+            auto hit = g_tune_cache.find(key);
+            if (hit != g_tune_cache.end() && !verbose) {
+                best_cfg = op.cfg;
+                best_cfg.mt = hit->second.mt; best_cfg.nt = hit->second.nt; best_cfg.lds = hit->second.lds;
+                best = 0.f;
+            } else
+            for (int fam = lds_ok ? 1 : 0; fam <= (lds_ok ? 1 : 0); fam++)
+                for (int mt = 1; mt <= 4; mt *= 2)
+                    for (int nt = 1; nt <= 4; nt *= 2) {
+                        if (op.cout_pad % (16 * nt) != 0) continue;
+                        ConvCfg c = op.cfg;
+                        c.mt = mt; c.nt = nt; c.lds = fam == 1;
+                        bool ok = true;
+                        for (int i = 0; i < 2 && ok; i++) ok = run_conv(op, c, a, counts[pass], e->stream);
+                        if (!ok) continue;
+                        float ms = 1e30f;   // best of 3 bursts of 4
+                        for (int rep = 0; rep < 3; rep++) {
+                            HIP_TRY(hipEventRecord(ea, e->stream));
+                            for (int i = 0; i < 4; i++) run_conv(op, c, a, counts[pass], e->stream);
+                            HIP_TRY(hipEventRecord(eb, e->stream));
+                            HIP_TRY(hipEventSynchronize(eb));
+                            float t = 0.f;
+                            HIP_TRY(hipEventElapsedTime(&t, ea, eb));
+                            ms = t < ms ? t : ms;
+                        }
+                        if (verbose) {
+                            char nm[48];
+                            cfg_name(c, nm, sizeof nm);
+                            fprintf(stderr, "[autotune] %-22s count=%-2d %-28s %8.2f us\n", op.layer.c_str(), counts[pass], nm, ms / 4 * 1e3);
+                        }
+                        if (ms < best) { best = ms; best_cfg = c; }
+                    }
+            g_tune_cache[key] = best_cfg;
+            if (pass == 0) { op.cfg = best_cfg; cfg_name(op.cfg, op.kname, sizeof op.kname); }
+            else { op.cfg_one = best_cfg; cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
+            if (e->cfg.num_slots == 1) { op.cfg_one = op.cfg; cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
         }
     }
     (void)hipEventDestroy(ea);
@@ -726,7 +804,7 @@ static PostArgs post_args(const irmv_engine *e, int first)
     p.first = first;
     p.boxes = e->boxes + (size_t)first * e->A * 4;
     p.keys = e->keys + (size_t)first * kCandCap;
-    p.counts = e->counts + first;
+    p.counts = e->counts + (size_t)first * kCountStride;
     p.dets = e->dets_dev + (size_t)first * e->cfg.max_det;
     p.fout = e->fout_dev + first;
     return p;
@@ -738,7 +816,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     hipStream_t s = e->stream;
     const int net = e->cfg.net_size;
     (void)flags;
-    HIP_TRY(hipMemsetAsync(e->counts + first, 0, (size_t)count * 4, s));
+    HIP_TRY(hipMemsetAsync(e->counts + (size_t)first * kCountStride, 0, (size_t)count * kCountStride * 4, s));
     const PostArgs pa = post_args(e, first);
     for (const Op &op : e->ops) {
         if (post_only && op.kind != OP_DECODE && op.kind != OP_NMS) continue;
@@ -771,7 +849,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             ConvArgs a;
             fill_conv_args(e, op, first, count, a);
             const ConvCfg &cc = (count == 1 && e->cfg.num_slots > 1) ? op.cfg_one : op.cfg;
-            if (!launch_conv(cc, a, s)) return fail(IRMV_ERR_ARG, std::string("no conv kernel for ") + op.kname + " (" + op.layer + ")");
+            if (!run_conv(op, cc, a, count, s)) return fail(IRMV_ERR_ARG, std::string("no conv kernel for ") + op.kname + " (" + op.layer + ")");
             break;
         }
         case OP_POOL: {

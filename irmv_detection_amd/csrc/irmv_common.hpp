@@ -17,6 +17,8 @@ constexpr int kClsOff = 64;
 constexpr int kKptOff = 80;
 constexpr int kCandCap = 8192; // == IRMV_CAND_CAP
 constexpr int kMaxDetCap = 256;
+constexpr int kCountStride = 32; // ints between per-frame candidate counters: one 128-B line each, so the
+                                 // decode kernel's atomics of different frames do not serialise on one line
 
 // ---- preprocess ------------------------------------------------------------
 // One bilinear tap table entry per destination coordinate (built on the host
@@ -69,10 +71,13 @@ struct ConvArgs {
     int pair;           // weight rows packed with the paired-tile channel permutation
 };
 
-struct ConvCfg { int ks, stride, mt, nt; bool cin16; int act; bool out_f32; };
+struct ConvCfg { int ks, stride, mt, nt; bool cin16; int act; bool out_f32; bool lds; };
 // returns false if no instantiation exists for cfg
 bool launch_conv(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 const char *conv_cfg_name(const ConvCfg &cfg, char *buf, int n);
+// LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt
+size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max);
+bool launch_conv_lds(int stride, int mt, int nt, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s);
 
 // SPPF pooling chain: slice 0 (C ch) of [B][H][W][4C] -> slices 1..3 (5x5, 9x9, 13x13 max)
 void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s);
@@ -99,7 +104,7 @@ struct PostArgs {
     int slots_total, first;   // level block offset = lvl_base * slots_total records; this step starts at slot `first`
     float *boxes;             // [B][A][4]
     unsigned long long *keys; // [B][kCandCap]
-    int *counts;              // [B]
+    int *counts;              // [B][kCountStride]
     DevDet *dets;             // [B][max_det]
     DevFrameOut *fout;        // [B]
     int net, A, nc, nk;

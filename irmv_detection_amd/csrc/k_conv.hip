@@ -241,6 +241,229 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
     return buf;
 }
 
+// ---------------------------------------------------------------------------
+// LDS-staged 3x3 convolution (stride 1 or 2, Cin % 32 == 0, SiLU, fp16 out).
+//
+// The direct kernel above re-reads every weight fragment in every wave and every
+// input pixel once per filter tap, all through L1/L2; on the 20x20..80x80 layers
+// that traffic, not the matrix cores, sets the time.  Here a workgroup owns a run
+// of 64*MT consecutive output pixels of ONE image and NT*16 output channels, and
+// walks Cin in chunks of 32 channels.  Per chunk it stages in LDS, once:
+//   * the input patch = all input rows its pixels touch, with halo, 32 channels
+//     per pixel, 96-byte pixel stride (64 B data + 32 B pad: the b128 fragment
+//     reads of the 16 lanes of a group then hit 16 distinct 16-byte slots);
+//   * the weight slab of the chunk for all 9 taps, already in MFMA fragment order
+//     (host-packed [n-block][chunk][tap][tile][lane][8], one contiguous 9*NT KiB).
+// All four waves then read their A/B fragments from LDS with conflict-free
+// ds_read_b128: weights are fetched from L2 once per workgroup instead of once
+// per wave, input pixels once instead of nine times.  The next chunk's global
+// loads are issued into registers before the current chunk's MFMAs (issue-early /
+// write-late), so HBM/L2 latency hides under the matrix work.
+// K order is (chunk, tap); zero padding = zeroed halo pixels.
+// ---------------------------------------------------------------------------
+constexpr int kPixStride = 96;  // bytes per staged pixel (32 ch fp16 + pad)
+
+template <int STRIDE, int MT, int NT>
+__global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_per_img, int patch_rows_max)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TPX = 64 * MT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    const int g = lane >> 4, r = lane & 15;
+    const int img = blockIdx.x / tiles_per_img, tile = blockIdx.x - img * tiles_per_img;
+    const int nblk = blockIdx.y;
+    const int HWo = a.Hout * a.Wout;
+    const int m0 = tile * TPX, m1 = min(m0 + TPX, HWo);          // pixel range in this image
+    const int y0 = m0 / a.Wout, y1 = (m1 - 1) / a.Wout;
+    const int PW = a.Win + 2, PR = (y1 - y0) * STRIDE + 3;
+    const int iy_base = y0 * STRIDE - 1;
+    unsigned char *s_patch = smem;
+    half8 *s_w = reinterpret_cast<half8 *>(smem + (size_t)patch_rows_max * PW * kPixStride);
+    const int chunks = a.Cin >> 5;
+    const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+
+    // this lane's output pixels and their patch coordinates
+    int poff[MT], mloc[MT];
+    bool mv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int m = m0 + (wave * MT + mt) * 16 + r;
+        mv[mt] = m < m1;
+        mloc[mt] = mv[mt] ? m : m0;
+        const int oy = mloc[mt] / a.Wout, ox = mloc[mt] - oy * a.Wout;
+        poff[mt] = (((oy - y0) * STRIDE) * PW + ox * STRIDE) * kPixStride + g * 16;
+    }
+
+    // staging plan: element e -> (pixel, 16-byte quarter); weights: 9*NT*64 half8 per chunk
+    constexpr int PMAX = 12;                      // patch 16-B pieces per thread (host guarantees the fit)
+    constexpr int WPT = (9 * NT * 64 + 255) / 256; // weight half8 per thread
+    const int n_pe = PR * PW * 4;
+    const half_t *src_p[PMAX];
+    int dst_p[PMAX];
+    bool val_p[PMAX], use_p[PMAX];
+#pragma unroll
+    for (int i = 0; i < PMAX; i++) {
+        const int e = tid + i * 256;
+        use_p[i] = e < n_pe;
+        const int pix = use_p[i] ? (e >> 2) : 0, q = e & 3;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int iy = iy_base + pr, ix = pc - 1;
+        val_p[i] = use_p[i] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        src_p[i] = a.s0.p + ((size_t)(img * a.Hin + (val_p[i] ? iy : 0)) * a.Win + (val_p[i] ? ix : 0)) * a.s0.ld + q * 8;
+        dst_p[i] = pix * kPixStride + q * 16;
+    }
+    const half8 *wsrc = reinterpret_cast<const half8 *>(wl) + (size_t)nblk * chunks * (9 * NT * 64);
+
+    half8 rp[PMAX], rw[WPT];
+    auto issue_loads = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < PMAX; i++) {
+            rp[i] = zero8;
+            if (val_p[i]) rp[i] = *reinterpret_cast<const half8 *>(src_p[i] + chunk * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; i++) {
+            const int e = tid + i * 256;
+            if (e < 9 * NT * 64) rw[i] = wsrc[(size_t)chunk * (9 * NT * 64) + e];
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < PMAX; i++)
+            if (use_p[i]) *reinterpret_cast<half8 *>(s_patch + dst_p[i]) = rp[i];
+#pragma unroll
+        for (int i = 0; i < WPT; i++) {
+            const int e = tid + i * 256;
+            if (e < 9 * NT * 64) s_w[e] = rw[i];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(0);
+    for (int chunk = 0; chunk < chunks; chunk++) {
+        write_lds();
+        __syncthreads();
+        if (chunk + 1 < chunks) issue_loads(chunk + 1);   // in flight under the MFMAs below
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int toff = (kh * PW + kw) * kPixStride;
+            half8 A[NT], B[MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) A[nt] = s_w[(tap * NT + nt) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) B[mt] = *reinterpret_cast<const half8 *>(s_patch + poff[mt] + toff);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[nt], B[mt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue (bias, SiLU, shortcut, fp16, NHWC store)
+    const int nt0 = nblk * NT;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        if (!mv[mt]) continue;
+        const size_t m = (size_t)img * HWo + mloc[mt];
+        if constexpr (NT % 2 == 0) {   // pair-packed (host guarantees): 8 contiguous channels per lane
+#pragma unroll
+            for (int u = 0; u < NT / 2; u++) {
+                const int c0 = (nt0 / 2 + u) * 32 + g * 8;
+                float vals[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    vals[i] = acc[mt][2 * u][i] + a.bias[c0 + i];
+                    vals[4 + i] = acc[mt][2 * u + 1][i] + a.bias[c0 + 4 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
+                if (a.res) {
+                    const half8 rv = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + c0);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) vals[i] += (float)rv[i];
+                }
+                half8 o;
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
+                *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = o;
+            }
+        } else {
+            const int t = nt0;
+            const int c0 = a.pair ? ((t >> 1) * 32 + g * 8 + (t & 1) * 4) : (t * 16 + g * 4);
+            float vals[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                vals[i] = acc[mt][0][i] + a.bias[c0 + i];
+                vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
+            }
+            if (a.res) {
+                const half4 rv = *reinterpret_cast<const half4 *>(a.res + m * a.res_ld + c0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) vals[i] += (float)rv[i];
+            }
+            *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) =
+                (half4){(half_t)vals[0], (half_t)vals[1], (half_t)vals[2], (half_t)vals[3]};
+        }
+    }
+}
+
+// LDS bytes / eligibility of the LDS kernel for a layer; 0 = not eligible
+size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max)
+{
+    if (a.Cin % 32 != 0 || a.s1.C != 0 || a.s0.shift != 0) return 0;
+    if (!((nt == 1) || ((nt == 2 || nt == 4) && a.pair))) return 0;
+    if (a.cout_pad % (16 * nt) != 0) return 0;
+    const int tpx = 64 * mt;
+    const int rows = (tpx + a.Wout - 2) / a.Wout + 1;          // most output rows a run of tpx pixels can touch
+    const int pr = (rows - 1) * stride + 3;
+    const int pw = a.Win + 2;
+    if ((size_t)pr * pw * 4 > 12 * 256) return 0;               // staging plan: at most 12 pieces per thread
+    const size_t bytes = (size_t)pr * pw * kPixStride + (size_t)9 * nt * 1024;
+    if (bytes > 80 * 1024) return 0;                            // two workgroups per CU (one per CU measured slower than the direct kernel)
+    *patch_rows_max = pr;
+    return bytes;
+}
+
+template <int STRIDE, int MT, int NT>
+static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, size_t lds, int pr, hipStream_t s)
+{
+    const int HWo = a.Hout * a.Wout;
+    const int tiles = (HWo + 64 * MT - 1) / (64 * MT);
+    static bool attr_set = false;   // one flag per instantiation
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT>), dim3(tiles * batch, a.cout_pad / (16 * NT)), dim3(256), lds, s, a, wl,
+                       tiles, pr);
+}
+
+bool launch_conv_lds(int stride, int mt, int nt, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s)
+{
+    int pr = 0;
+    const size_t lds = conv_lds_bytes(a, stride, mt, nt, &pr);
+    if (!lds) return false;
+#define IRMV_LDS(ST_, MT_, NT_)                                                   \
+    if (stride == ST_ && mt == MT_ && nt == NT_) {                                \
+        launch_lds_inst<ST_, MT_, NT_>(a, wl, batch, lds, pr, s);                 \
+        return true;                                                              \
+    }
+    IRMV_LDS(1, 1, 1) IRMV_LDS(1, 2, 1) IRMV_LDS(1, 4, 1)
+    IRMV_LDS(1, 1, 2) IRMV_LDS(1, 2, 2) IRMV_LDS(1, 4, 2) IRMV_LDS(1, 1, 4) IRMV_LDS(1, 2, 4) IRMV_LDS(1, 4, 4)
+    IRMV_LDS(2, 1, 1) IRMV_LDS(2, 2, 1) IRMV_LDS(2, 4, 1)
+    IRMV_LDS(2, 1, 2) IRMV_LDS(2, 2, 2) IRMV_LDS(2, 4, 2) IRMV_LDS(2, 1, 4) IRMV_LDS(2, 2, 4) IRMV_LDS(2, 4, 4)
+#undef IRMV_LDS
+    return false;
+}
+
 // SPPF (SURVEY.md Appendix A "Blocks"): p1 = maxpool5(a), p2 = maxpool5(p1),
 // p3 = maxpool5(p2).  Stride-1 max pools compose, so p2 / p3 are the clipped 9x9 /
 // 13x13 window maxima of `a`, and every window maximum is separable.
@@ -376,7 +599,8 @@ void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s
 {
     // widest channel slab whose four [H*W][CW] fp16 images fit in LDS
     int cw = 0;
-    for (int c = 32; c >= 8; c >>= 1)
+    // (narrow slabs: more workgroups, and several fit per CU)
+    for (int c = 8; c <= 32; c <<= 1)
         if (C % c == 0 && (size_t)4 * H * W * c * 2 <= 150 * 1024) { cw = c; break; }
     if (cw) {
         const size_t lds = (size_t)4 * H * W * cw * 2;

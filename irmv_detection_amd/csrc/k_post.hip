@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
         const int c = 4 * q + i;
         const float logit = cl[i];
         if (c < a.nc && logit > a.logit_thr) {
-            const int idx = atomicAdd(&a.counts[b], 1);
+            const int idx = atomicAdd(&a.counts[b * kCountStride], 1);
             if (idx < kCandCap)
                 a.keys[(size_t)b * kCandCap + idx] =
                     ((unsigned long long)orderable(logit) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(an * a.nc + c));
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     __shared__ int s_kept;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_total = a.counts[b];
+    const int n_total = a.counts[b * kCountStride];
     const int n_stored = n_total < kCandCap ? n_total : kCandCap;
     const unsigned long long *gk = a.keys + (size_t)b * kCandCap;
     const unsigned long long *sorted;
