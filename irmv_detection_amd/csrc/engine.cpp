@@ -143,6 +143,7 @@ struct irmv_engine {
     int head_t[3] = {-1, -1, -1};
     float *head_all = nullptr;
     PnpConst *pnp_dev = nullptr;
+    long long *dbg_dev = nullptr;
     float *boxes = nullptr;
     unsigned long long *keys = nullptr;
     int *counts = nullptr;
@@ -163,6 +164,13 @@ irmv_engine::~irmv_engine()
 {
     if (cfg.device >= 0) (void)hipSetDevice(cfg.device);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (dbg_dev) {   // diagnostic: phase cycles of the last nms_pnp launch per slot (100 MHz s_memtime-independent clock64)
+        std::vector<long long> h((size_t)cfg.num_slots * 8);
+        if (hipMemcpy(h.data(), dbg_dev, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int s = 0; s < cfg.num_slots && s < 4; s++)
+                fprintf(stderr, "[nms stamps] slot %d: sort %lld masks %lld walk %lld out+pnp %lld cycles; n=%lld kept=%lld\n", s, h[s * 8 + 1] - h[s * 8 + 0],
+                        h[s * 8 + 2] - h[s * 8 + 1], h[s * 8 + 3] - h[s * 8 + 2], h[s * 8 + 4] - h[s * 8 + 3], h[s * 8 + 5], h[s * 8 + 6]);
+    }
     for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
     for (void *p : dev_allocs) (void)hipFree(p);
     if (src_host) (void)hipHostFree(src_host);
@@ -530,6 +538,12 @@ static int build_engine(irmv_engine *e)
     TRY(dev_alloc(e, (void **)&e->pnp_dev, sizeof(PnpConst)));
     HIP_TRY(hipMemcpy(e->pnp_dev, &pc, sizeof pc, hipMemcpyHostToDevice));
     p.pnp = e->pnp_dev;
+    p.dbg = nullptr;
+    if (getenv("IRMV_NMS_STAMPS")) {
+        TRY(dev_alloc(e, (void **)&e->dbg_dev, (size_t)S * 8 * sizeof(long long)));
+        HIP_TRY(hipMemset(e->dbg_dev, 0, (size_t)S * 8 * sizeof(long long)));
+        p.dbg = e->dbg_dev;
+    }
     HIP_TRY(hipDeviceSynchronize());
     return IRMV_OK;
 }
@@ -807,6 +821,7 @@ static PostArgs post_args(const irmv_engine *e, int first)
     p.counts = e->counts + (size_t)first * kCountStride;
     p.dets = e->dets_dev + (size_t)first * e->cfg.max_det;
     p.fout = e->fout_dev + first;
+    if (p.dbg) p.dbg += (size_t)first * 8;
     return p;
 }
 

@@ -114,6 +114,7 @@ struct PostArgs {
     float scale_x, scale_y, off_x, off_y;
     int armor_size;
     const PnpConst *pnp;      // device copy (keeps the kernel-argument struct out of scratch)
+    long long *dbg;           // optional [B][8] phase stamps of nms_pnp_kernel (diagnostic builds of the engine only)
 };
 void launch_decode(const PostArgs &a, int batch, hipStream_t s);
 void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s);

@@ -144,7 +144,8 @@ void launch_decode(const PostArgs &a, int batch, hipStream_t s)
     hipLaunchKernelGGL(decode_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a, batch);
 }
 
-__device__ __forceinline__ float iou_xyxy(const f32x4 a, const f32x4 b)
+// "IoU(a, b) > thr" as inter > thr * union (same expression as the oracle's iou_gt)
+__device__ __forceinline__ bool iou_gt(const f32x4 a, const f32x4 b, float thr)
 {
     const float ix1 = a[0] > b[0] ? a[0] : b[0];
     const float iy1 = a[1] > b[1] ? a[1] : b[1];
@@ -157,7 +158,7 @@ __device__ __forceinline__ float iou_xyxy(const f32x4 a, const f32x4 b)
     const float aa = (a[2] - a[0]) * (a[3] - a[1]);
     const float ab = (b[2] - b[0]) * (b[3] - b[1]);
     const float uni = (aa + ab) - inter;
-    return inter / uni;
+    return inter > thr * uni;
 }
 
 // ---------------------------------------------------------------------------
@@ -372,7 +373,8 @@ void launch_pnp_only(const PnpConst &c, const float *pts, int n, int armor_size,
 //   4. one lane per survivor: keypoints, parse_output scaling, fp64 IPPE PnP.
 // The greedy walk is exactly the oracle's: same comparisons, same order.
 // ---------------------------------------------------------------------------
-constexpr int kRankSortMax = 2048;
+constexpr int kRankSortMax = 2048;   // capacity of the rank-sort destination
+constexpr int kRankSortUse = 320;    // above this the O(n^2) rank sort loses to the bitonic network
 constexpr int kSupCap = 4096;   // candidates whose intra-block masks are precomputed
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -390,10 +392,11 @@ __device__ __forceinline__ unsigned long long block_sup_mask(f32x4 box, int cls,
     scls[lane] = cls;
     wave_lds_sync();
     unsigned long long sup = 0ull;
+#pragma unroll 8
     for (int j = 0; j < 64; j++) {
         const f32x4 bj = sbox[j];
         const int cj = scls[j];
-        if (j < lane && cj == cls && cls >= 0 && iou_xyxy(bj, box) > iou_thr) sup |= 1ull << j;
+        if (j < lane && cj == cls && cls >= 0 && iou_gt(bj, box, iou_thr)) sup |= 1ull << j;
     }
     wave_lds_sync();
     return sup;
@@ -401,7 +404,7 @@ __device__ __forceinline__ unsigned long long block_sup_mask(f32x4 box, int cls,
 
 __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
 {
-    __shared__ unsigned long long skeys[kCandCap];          // 64 KiB: candidate keys (bitonic sorts in place)
+    __shared__ __attribute__((aligned(16))) unsigned long long skeys[kCandCap];   // 64 KiB: candidate keys (bitonic sorts in place)
     __shared__ unsigned long long srank[kRankSortMax];      // 16 KiB: rank-sort destination
     __shared__ unsigned long long ssup[kSupCap];            // 32 KiB: intra-block suppression masks
     __shared__ f32x4 stage_box[16][64];                     // 16 KiB: per-wave block staging
@@ -414,26 +417,38 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     __shared__ int s_kept;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define IRMV_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[b * 8 + (k)] = clock64(); } while (0)
+    IRMV_STAMP(0);
     const int n_total = a.counts[b * kCountStride];
     const int n_stored = n_total < kCandCap ? n_total : kCandCap;
     const unsigned long long *gk = a.keys + (size_t)b * kCandCap;
     const unsigned long long *sorted;
     if (tid < 16) cls_cnt[tid] = 0;
 
-    if (n_stored <= kRankSortMax) {
+    if (n_stored <= kRankSortUse) {
         for (int i = tid; i < n_stored; i += blockDim.x) skeys[i] = gk[i];
         __syncthreads();
         // keys are unique, so "number of keys greater than mine" is a permutation
+        const int n8 = (n_stored + 7) & ~7;
+        for (int i = n_stored + tid; i < n8; i += blockDim.x) skeys[i] = 0ull;   // pad: never greater than a real key
+        __syncthreads();
         for (int i = tid; i < n_stored; i += blockDim.x) {
             const unsigned long long mine = skeys[i];
             int rank = 0;
-            for (int j = 0; j < n_stored; j++) rank += skeys[j] > mine ? 1 : 0;
+            for (int j = 0; j < n8; j += 8) {
+                const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(&skeys[j]);
+                const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 2]);
+                const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 4]);
+                const ulonglong2 k3 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 6]);
+                rank += (k0.x > mine) + (k0.y > mine) + (k1.x > mine) + (k1.y > mine) + (k2.x > mine) + (k2.y > mine) +
+                        (k3.x > mine) + (k3.y > mine);
+            }
             srank[rank] = mine;
         }
         __syncthreads();
         sorted = srank;
     } else {
-        int npow = kRankSortMax * 2;
+        int npow = 512;
         while (npow < n_stored) npow <<= 1;
         for (int i = tid; i < npow; i += blockDim.x) skeys[i] = i < n_stored ? gk[i] : 0ull;
         __syncthreads();
@@ -454,6 +469,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     }
     const int n = n_stored < a.pre_nms_cap ? n_stored : a.pre_nms_cap;
     const f32x4 *boxes = reinterpret_cast<const f32x4 *>(a.boxes) + (size_t)b * a.A;
+    IRMV_STAMP(1);
 
     // ---- 2. intra-block masks, one block per wave ----
     const int n_pre = n < kSupCap ? n : kSupCap;
@@ -468,6 +484,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         ssup[idx] = block_sup_mask(box, cls, lane, a.iou_thr, stage_box[wave], stage_cls[wave]);
     }
     __syncthreads();
+    IRMV_STAMP(2);
 
     // ---- 3. greedy walk on wave 0 ----
     if (wave == 0) {
@@ -486,7 +503,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             for (int j = 0; __any(j < mycnt); j++) {
                 if (j < mycnt) {
                     const int k = cls_list[cls][j];
-                    if (iou_xyxy(kept_box[k], box) > a.iou_thr) alive = false;
+                    if (iou_gt(kept_box[k], box, a.iou_thr)) alive = false;
                 }
             }
             const unsigned long long sup = start < n_pre ? ssup[idx]
@@ -494,16 +511,16 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             // sequential resolve, earliest first
             unsigned long long A = __ballot(alive);
             int taken = 0;
-            for (int j = 0; j < 64; j++) {
-                if ((A >> j) & 1ull) {
-                    if (kept + taken >= a.max_det) {
-                        A &= (1ull << j) - 1ull;   // cap reached: drop j and everything after
-                        break;
-                    }
-                    taken++;
-                    const unsigned long long col = __ballot((sup >> j) & 1ull);
-                    A &= ~col;
+            for (unsigned long long todo = A; todo;) {          // walk the still-alive candidates in order
+                const int j = __ffsll((long long)todo) - 1;
+                if (kept + taken >= a.max_det) {
+                    A &= (1ull << j) - 1ull;                      // cap reached: drop j and everything after
+                    break;
                 }
+                taken++;
+                const unsigned long long col = __ballot((sup >> j) & 1ull);   // lanes that j suppresses (all > j)
+                A &= ~col;
+                todo = A & ~((2ull << j) - 1ull);
             }
             const bool mine = (A >> lane) & 1ull;
             const int pos = kept + __popcll(A & ((1ull << lane) - 1ull));
@@ -512,18 +529,14 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
                 kept_cls[pos] = cls;
                 kept_key[pos] = key;
             }
-            for (int c = 0; c < a.nc; c++) {
-                const unsigned long long mc = __ballot(mine && cls == c);
-                if (mine && cls == c) cls_list[c][cls_cnt[c] + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)pos;
-                wave_lds_sync();
-                if (lane == 0 && mc) cls_cnt[c] += __popcll(mc);
-            }
+            if (mine) cls_list[cls][atomicAdd(&cls_cnt[cls], 1)] = (unsigned short)pos;   // order within a class is irrelevant
             wave_lds_sync();
             kept += __popcll(A);
         }
         if (lane == 0) s_kept = kept;
     }
     __syncthreads();
+    IRMV_STAMP(3);
     const int kept = s_kept;
     if (tid == 0) {
         DevFrameOut fo;
@@ -579,6 +592,10 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         }
         a.dets[(size_t)b * a.max_det + j] = d;
     }
+    __syncthreads();
+    IRMV_STAMP(4);
+    if (a.dbg && tid == 0) { a.dbg[b * 8 + 5] = n_total; a.dbg[b * 8 + 6] = kept; }
+#undef IRMV_STAMP
 }
 
 void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s)

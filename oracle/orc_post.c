@@ -224,7 +224,11 @@ int orc_decode_candidates(const float *head, int net, int nc, int nk, float scor
     return n;
 }
 
-static inline float iou_xyxy(const float *a, const float *b)
+/* "IoU(a, b) > thr" without the division: inter > thr * union.  (Boxes decoded from
+ * DFL distances have x2 >= x1, y2 >= y1, so union >= inter >= 0; union == 0 gives
+ * false, as the quotient's NaN would.)  The HIP kernel evaluates the same
+ * expression, so survivor sets are bit-reproducible. */
+static inline int iou_gt(const float *a, const float *b, float thr)
 {
     float ix1 = a[0] > b[0] ? a[0] : b[0];
     float iy1 = a[1] > b[1] ? a[1] : b[1];
@@ -237,7 +241,7 @@ static inline float iou_xyxy(const float *a, const float *b)
     float aa = (a[2] - a[0]) * (a[3] - a[1]);
     float ab = (b[2] - b[0]) * (b[3] - b[1]);
     float uni = (aa + ab) - inter;
-    return inter / uni;
+    return inter > thr * uni;
 }
 
 /* EfficientNMS walk: emit unless an already emitted box
@@ -250,7 +254,7 @@ int orc_nms_sorted(const float *boxes, const int *classes, int n, float iou_thr,
         int ok = 1;
         for (int j = 0; j < kept; j++) {
             int q = keep_idx[j];
-            if (classes[q] == classes[i] && iou_xyxy(boxes + (size_t)q * 4, boxes + (size_t)i * 4) > iou_thr) {
+            if (classes[q] == classes[i] && iou_gt(boxes + (size_t)q * 4, boxes + (size_t)i * 4, iou_thr)) {
                 ok = 0;
                 break;
             }
