@@ -114,6 +114,9 @@ struct Op {
     float *bias = nullptr;
     double flops = 0, bytes = 0;  // per frame
     bool pair = false;
+    int lane = 0;      // 0 = main stream; 1..3 = Detect branch (box / cls / kpt) side streams in the captured graph
+    int level = -1;    // Detect level of a head op: it may start as soon as P(level) exists
+    int signal = -1;   // >= 0: this op produces P(signal); side lanes wait on its event
     char kname[48] = {0};
 };
 
@@ -132,6 +135,9 @@ struct irmv_engine {
     int lvl_hw[3] = {0, 0, 0}, lvl_base[3] = {0, 0, 0};
     size_t frame_bytes = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // Detect-branch lanes (only ever used under stream capture)
+    hipEvent_t ev_level[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
+    bool fork_head = false;   // opt-in (IRMV_FORK_HEAD=1): measured 11 % SLOWER than the linear graph at 16 frames/step
     uint8_t *src_host = nullptr;  // pinned [S][frame]
     uint8_t *src_dev = nullptr;   // [S][frame]
     uint8_t *rot_dev = nullptr;   // [frame]
@@ -176,6 +182,11 @@ irmv_engine::~irmv_engine()
     if (src_host) (void)hipHostFree(src_host);
     if (dets_host) (void)hipHostFree(dets_host);
     if (fout_host) (void)hipHostFree(fout_host);
+    for (int i = 0; i < 3; i++) {
+        if (side[i]) (void)hipStreamDestroy(side[i]);
+        if (ev_level[i]) (void)hipEventDestroy(ev_level[i]);
+        if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+    }
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -367,6 +378,12 @@ static int build_engine(irmv_engine *e)
     const int net = c.net_size, S = c.num_slots;
     HIP_TRY(hipSetDevice(c.device));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 3; i++) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_level[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+    }
+    { const char *f = getenv("IRMV_FORK_HEAD"); e->fork_head = f && f[0] == '1'; }
     e->frame_bytes = (size_t)c.src_width * c.src_height * 3;
     HIP_TRY(hipHostMalloc((void **)&e->src_host, e->frame_bytes * S, hipHostMallocDefault));
     memset(e->src_host, 0, e->frame_bytes * S);
@@ -454,10 +471,13 @@ static int build_engine(irmv_engine *e)
     TRY(add_conv(e, "model.9.cv2", SegRef{s9, 0, 512, 0}, SegRef{}, s32, s32, a9, 0));
     TRY(add_c2f(e, "model.12", SegRef{a9, 0, 256, 1}, SegRef{a6, 0, 128, 0}, s16, s16, 128, 1, false, a12));
     TRY(add_c2f(e, "model.15", SegRef{a12, 0, 128, 1}, SegRef{a4, 0, 64, 0}, s8, s8, 64, 1, false, a15));
+    e->ops.back().signal = 0;
     TRY(add_conv(e, "model.16.conv", SegRef{a15, 0, 64, 0}, SegRef{}, s8, s8, a16, 0));
     TRY(add_c2f(e, "model.18", SegRef{a16, 0, 64, 0}, SegRef{a12, 0, 128, 0}, s16, s16, 128, 1, false, a18));
+    e->ops.back().signal = 1;
     TRY(add_conv(e, "model.19.conv", SegRef{a18, 0, 128, 0}, SegRef{}, s16, s16, a19, 0));
     TRY(add_c2f(e, "model.21", SegRef{a19, 0, 128, 0}, SegRef{a9, 0, 256, 0}, s32, s32, 256, 1, false, a21));
+    e->ops.back().signal = 2;
 
     // Detect head: per level one fp32 record of kHeadRec per anchor: box 64 | cls 16 | kpt 16
     const int P[3] = {a15, a18, a21}, PC[3] = {64, 128, 256}, PS[3] = {s8, s16, s32};
@@ -492,6 +512,7 @@ static int build_engine(irmv_engine *e)
             TRY(add_conv(e, pre + ".0", SegRef{P[i], 0, PC[i], 0}, SegRef{}, PS[i], PS[i], t1, 0));
             TRY(add_conv(e, pre + ".1", SegRef{t1, 0, mid[b], 0}, SegRef{}, PS[i], PS[i], t2, 0));
             TRY(add_conv(e, pre + ".2", SegRef{t2, 0, mid[b], 0}, SegRef{}, PS[i], PS[i], e->head_t[i], off[b]));
+            for (size_t k = e->ops.size() - 3; k < e->ops.size(); k++) { e->ops[k].lane = 1 + b; e->ops[k].level = i; }
         }
 
     // ---- post-processing buffers ----
@@ -828,13 +849,34 @@ static PostArgs post_args(const irmv_engine *e, int first)
 // Enqueue one step on the engine stream.  ev != nullptr: bracket every kernel with events.
 static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bool post_only, std::vector<EvRec> *ev)
 {
-    hipStream_t s = e->stream;
     const int net = e->cfg.net_size;
-    (void)flags;
-    HIP_TRY(hipMemsetAsync(e->counts + (size_t)first * kCountStride, 0, (size_t)count * kCountStride * 4, s));
+    const bool capturing = (flags & 0x40000000u) != 0;
+    HIP_TRY(hipMemsetAsync(e->counts + (size_t)first * kCountStride, 0, (size_t)count * kCountStride * 4, e->stream));
     const PostArgs pa = post_args(e, first);
+    // Under capture the three Detect branches ride side streams: branch chains of level i depend only on
+    // P(i), so the big P3 head convs overlap the small neck / P4 / P5 layers in the replayed graph.
+    const bool fork = capturing && e->fork_head && !post_only;
+    bool lane_used[3] = {false, false, false};
+    int lane_level[3] = {-1, -1, -1};
     for (const Op &op : e->ops) {
         if (post_only && op.kind != OP_DECODE && op.kind != OP_NMS) continue;
+        hipStream_t s = e->stream;
+        if (fork && op.lane > 0) {
+            const int ln = op.lane - 1;
+            s = e->side[ln];
+            if (lane_level[ln] != op.level) {   // first op of this level on this lane: wait for P(level)
+                HIP_TRY(hipStreamWaitEvent(s, e->ev_level[op.level], 0));
+                lane_level[ln] = op.level;
+            }
+            lane_used[ln] = true;
+        }
+        if (fork && op.kind == OP_DECODE) {     // join the lanes before post-processing
+            for (int ln = 0; ln < 3; ln++)
+                if (lane_used[ln]) {
+                    HIP_TRY(hipEventRecord(e->ev_join[ln], e->side[ln]));
+                    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join[ln], 0));
+                }
+        }
         EvRec r{};
         if (ev) {
             HIP_TRY(hipEventCreate(&r.a));
@@ -876,6 +918,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         case OP_NMS: launch_nms_pnp(pa, count, s); break;
         }
         HIP_TRY(hipGetLastError());
+        if (fork && op.signal >= 0) HIP_TRY(hipEventRecord(e->ev_level[op.signal], e->stream));
         if (ev) {
             HIP_TRY(hipEventRecord(r.b, s));
             ev->push_back(r);
@@ -916,7 +959,7 @@ static int get_graph(irmv_engine *e, int first, int count, uint32_t flags, bool 
     if (it != e->graphs.end()) { *out = it->second; return IRMV_OK; }
     hipGraph_t g = nullptr;
     HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_step(e, first, count, flags, post_only, nullptr);
+    int rc = enqueue_step(e, first, count, flags | 0x40000000u, post_only, nullptr);
     hipError_t ce = hipStreamEndCapture(e->stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (ce != hipSuccess) return fail(IRMV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
@@ -1141,6 +1184,9 @@ struct irmv_pnp {
     int device = 0;
     PnpConst c{};
     hipStream_t stream = nullptr;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // Detect-branch lanes (only ever used under stream capture)
+    hipEvent_t ev_level[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
+    bool fork_head = false;   // opt-in (IRMV_FORK_HEAD=1): measured 11 % SLOWER than the linear graph at 16 frames/step
     float *pts = nullptr;
     double *rvec = nullptr, *tvec = nullptr;
     int32_t *ok = nullptr;
