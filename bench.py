@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames-per-step", type=int, default=16)
+    ap.add_argument("--frames-per-step", type=int, default=32)
     ap.add_argument("--src", default="1280x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96)
@@ -178,9 +178,15 @@ def main():
         conv_ms = sum(v["ms"] for k, v in agg.items() if v["flops"] > 0) / len(prof_runs)
         conv_fl = sum(v["flops"] for k, v in agg.items() if v["flops"] > 0) / len(prof_runs)
         pre = agg.get("preprocess")
+        # HBM traffic of that kernel from the separate rocprofv3 --pmc passes (scripts/collect_traffic.py), if collected
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as tf:
+                traffic = (json.load(tf).get(dom_name) or {}).get("hbm_bytes_per_launch")
         roofline = dict(bound="mfma", kernel=dom_name, launches_per_step=dom["n"] // len(prof_runs),
                         avg_launch_ms=round(avg_ms, 5), achieved=round(achieved, 3), peak=PEAK_FP16_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP16_TFLOPS, 5), traffic=None,
+                        unit="TFLOP/s", frac=round(achieved / PEAK_FP16_TFLOPS, 5), traffic=traffic,
                         all_conv_tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
                         step_kernel_ms_eager=round(sum(v["ms"] for v in agg.values()) / len(prof_runs), 4))
         if pre:

@@ -426,6 +426,7 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
     const int pr = (rows - 1) * stride + 3;
     const int pw = a.Win + 2;
     if ((size_t)pr * pw * 4 > 12 * 256) return 0;               // staging plan: at most 12 pieces per thread
+    if ((size_t)pr * pw * kPixStride > 48 * 1024) return 0;     // wide stride-2 patches: the direct kernel measured faster
     const size_t bytes = (size_t)pr * pw * kPixStride + (size_t)9 * nt * 1024;
     if (bytes > 80 * 1024) return 0;                            // two workgroups per CU (one per CU measured slower than the direct kernel)
     *patch_rows_max = pr;
