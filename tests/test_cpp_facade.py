@@ -35,8 +35,10 @@ def test_triple_buffer_handoff_terminates_and_never_tears():
 
 
 def test_reference_style_code_compiles_against_the_facade():
-    # built here so the binary travels to the GPU box with the tree
+    # built here so the binaries travel to the GPU box with the tree
     exe = _compile("yolo_test.cpp", os.path.join(BIN, "yolo_test"), True)
+    assert os.path.exists(exe)
+    exe = _compile("camera_stream_test.cpp", os.path.join(BIN, "camera_stream_test"), True)
     assert os.path.exists(exe)
 
 
@@ -63,3 +65,21 @@ def test_reference_test_flow_on_gpu(tmp_path, blob, frame0):
     assert m.group(1) == m.group(2) == "1" and float(m.group(3)) < 1e-9        # standalone PnPSolver == fused PnP
     assert np.allclose([float(m.group(i)) for i in (4, 5, 6)], arm[0].tvec, atol=1e-8)
     assert re.search(r"detect_ms avg (\S+) max (\S+)", txt) and float(re.search(r"max (\S+) min", txt).group(1)) < 30.0
+
+
+@pytest.mark.gpu
+def test_camera_stream_330fps_through_the_triple_buffer(tmp_path, blob):
+    """BASELINE configs[2]: paced 330 FPS synthetic camera -> pinned slots -> async H2D -> detect."""
+    from irmv_detection_amd import frames
+    exe = os.path.join(BIN, "camera_stream_test")
+    if not os.path.exists(exe):
+        exe = _compile("camera_stream_test.cpp", exe, True)
+    (tmp_path / "yolov7.irmw").write_bytes(blob)
+    frames.synthetic_batch(0, 8).tofile(tmp_path / "frames.bin")
+    out = subprocess.run([exe, str(tmp_path / "yolov7.onnx"), str(tmp_path / "frames.bin"), "8", "2.0"], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"paced330 producer_fps (\S+) consumer_fps (\S+) lat_ms mean (\S+) p99 (\S+)", out.stdout)
+    assert abs(float(m.group(1)) - 330) < 33 and float(m.group(2)) > 0.9 * float(m.group(1)) and float(m.group(4)) < 10.0
+    m = re.search(r"unpaced producer_fps (\S+) consumer_fps (\S+)", out.stdout)
+    assert float(m.group(2)) > 330        # un-paced, the consumer keeps up with far more than the camera rate
