@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
     constexpr int PMAX = 12;                      // patch 16-B pieces per thread (host guarantees the fit)
     constexpr int WPT = (9 * NT * 64 + 255) / 256; // weight half8 per thread
     const int n_pe = PR * PW * 4;
+    const float inv_pw = 1.0f / (float)PW;
     const half_t *src_p[PMAX];
     int dst_p[PMAX];
     bool val_p[PMAX], use_p[PMAX];
@@ -306,7 +307,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
         const int e = tid + i * 256;
         use_p[i] = e < n_pe;
         const int pix = use_p[i] ? (e >> 2) : 0, q = e & 3;
-        const int pr = pix / PW, pc = pix - pr * PW;
+        int pr = (int)((float)pix * inv_pw);               // pix < 2^16: one correction step makes the quotient exact
+        pr -= (pr * PW > pix) ? 1 : 0;
+        pr += ((pr + 1) * PW <= pix) ? 1 : 0;
+        const int pc = pix - pr * PW;
         const int iy = iy_base + pr, ix = pc - 1;
         val_p[i] = use_p[i] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
         src_p[i] = a.s0.p + ((size_t)(img * a.Hin + (val_p[i] ? iy : 0)) * a.Win + (val_p[i] ? ix : 0)) * a.s0.ld + q * 8;
@@ -426,7 +430,7 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
     const int pr = (rows - 1) * stride + 3;
     const int pw = a.Win + 2;
     if ((size_t)pr * pw * 4 > 12 * 256) return 0;               // staging plan: at most 12 pieces per thread
-    if ((size_t)pr * pw * kPixStride > 48 * 1024) return 0;     // wide stride-2 patches: the direct kernel measured faster
+    if (stride == 2 && (size_t)pr * pw * kPixStride > 48 * 1024) return 0;   // wide stride-2 patches: the direct kernel measured faster
     const size_t bytes = (size_t)pr * pw * kPixStride + (size_t)9 * nt * 1024;
     if (bytes > 80 * 1024) return 0;                            // two workgroups per CU (one per CU measured slower than the direct kernel)
     *patch_rows_max = pr;
