@@ -246,10 +246,12 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 //
 // The direct kernel above re-reads every weight fragment in every wave and every
 // input pixel once per filter tap, all through L1/L2; on the 20x20..80x80 layers
-// that traffic, not the matrix cores, sets the time.  Here a workgroup owns a run
-// of 64*MT consecutive output pixels of ONE image and NT*16 output channels, and
-// walks Cin in chunks of 32 channels.  Per chunk it stages in LDS, once:
-//   * the input patch = all input rows its pixels touch, with halo, 32 channels
+// that traffic, not the matrix cores, sets the time.  Here a workgroup owns a 2-D
+// block of 64*MT output pixels of ONE image (RH rows x 16 / 8 / 4 columns, whichever
+// divides the width: halo overhead ~1.4x instead of the 3x of full-width rows) and
+// NT*16 output channels, and walks Cin in chunks of 32 channels.  Per chunk it
+// stages in LDS, once:
+//   * the input patch = the block's input pixels with halo, 32 channels
 //     per pixel, 96-byte pixel stride (64 B data + 32 B pad: the b128 fragment
 //     reads of the 16 lanes of a group then hit 16 distinct 16-byte slots);
 //   * the weight slab of the chunk for all 9 taps, already in MFMA fragment order
@@ -263,38 +265,61 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 // ---------------------------------------------------------------------------
 constexpr int kPixStride = 96;  // bytes per staged pixel (32 ch fp16 + pad)
 
-template <int STRIDE, int MT, int NT>
-__global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_per_img, int patch_rows_max)
+template <int STRIDE, int MT, int NT, bool TILE2D>
+__global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TPX = 64 * MT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
     const int g = lane >> 4, r = lane & 15;
-    const int img = blockIdx.x / tiles_per_img, tile = blockIdx.x - img * tiles_per_img;
+    // Pixel ownership, two schemes:
+    //  TILE2D  : a 2-D block.  An MFMA tile is (16 / TWc) rows x TWc columns, a wave stacks MT of them
+    //            in y, the 4 waves stack in y again -> RH x TWc output pixels, halo (RH*s+2) x (TWc*s+2):
+    //            ~1.4x halo overhead.  Used when the block shape tiles the image exactly.
+    //  row run : 64*MT consecutive pixels in row-major order (tiles_x = runs per image): no masked
+    //            lanes on 20x20 / 40x40 maps whose sides are not multiples of the block, at the price
+    //            of staging full-width rows.
+    const int img = blockIdx.x / (tiles_x * tiles_y), tile = blockIdx.x - img * (tiles_x * tiles_y);
     const int nblk = blockIdx.y;
     const int HWo = a.Hout * a.Wout;
-    const int m0 = tile * TPX, m1 = min(m0 + TPX, HWo);          // pixel range in this image
-    const int y0 = m0 / a.Wout, y1 = (m1 - 1) / a.Wout;
-    const int PW = a.Win + 2, PR = (y1 - y0) * STRIDE + 3;
-    const int iy_base = y0 * STRIDE - 1;
+    int PW, PR, iy_base, ix_base;
+    int poff[MT], mloc[MT];
+    bool mv[MT];
+    if constexpr (TILE2D) {
+        const int TWc = 1 << twc_log2, trows = 16 >> twc_log2;
+        const int RH = 4 * MT * trows;
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int y0 = tyi * RH, x0 = txi * TWc;
+        PW = TWc * STRIDE + 2; PR = RH * STRIDE + 2;
+        iy_base = y0 * STRIDE - 1; ix_base = x0 * STRIDE - 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int ly = (wave * MT + mt) * trows + (r >> twc_log2), lx = r & (TWc - 1);
+            const int oy = y0 + ly, ox = x0 + lx;
+            mv[mt] = oy < a.Hout && ox < a.Wout;
+            mloc[mt] = mv[mt] ? oy * a.Wout + ox : 0;
+            poff[mt] = ((ly * STRIDE) * PW + lx * STRIDE) * kPixStride + g * 16;
+        }
+    } else {
+        constexpr int TPX = 64 * MT;
+        const int m0 = tile * TPX, m1 = min(m0 + TPX, HWo);
+        const int y0 = m0 / a.Wout, y1 = (m1 - 1) / a.Wout;
+        PW = a.Win + 2; PR = (y1 - y0) * STRIDE + 3;
+        iy_base = y0 * STRIDE - 1; ix_base = -1;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int m = m0 + (wave * MT + mt) * 16 + r;
+            mv[mt] = m < m1;
+            mloc[mt] = mv[mt] ? m : m0;
+            const int oy = mloc[mt] / a.Wout, ox = mloc[mt] - oy * a.Wout;
+            poff[mt] = (((oy - y0) * STRIDE) * PW + ox * STRIDE) * kPixStride + g * 16;
+        }
+    }
     unsigned char *s_patch = smem;
-    half8 *s_w = reinterpret_cast<half8 *>(smem + (size_t)patch_rows_max * PW * kPixStride);
+    half8 *s_w = reinterpret_cast<half8 *>(smem + (size_t)a_patch_bytes);
     const int chunks = a.Cin >> 5;
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 
-    // this lane's output pixels and their patch coordinates
-    int poff[MT], mloc[MT];
-    bool mv[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        const int m = m0 + (wave * MT + mt) * 16 + r;
-        mv[mt] = m < m1;
-        mloc[mt] = mv[mt] ? m : m0;
-        const int oy = mloc[mt] / a.Wout, ox = mloc[mt] - oy * a.Wout;
-        poff[mt] = (((oy - y0) * STRIDE) * PW + ox * STRIDE) * kPixStride + g * 16;
-    }
-
-    // staging plan: element e -> (pixel, 16-byte quarter); weights: 9*NT*64 half8 per chunk
+    // staging plan: element e -> (patch pixel, 16-byte quarter); weights: 9*NT*64 half8 per chunk
     constexpr int PMAX = 12;                      // patch 16-B pieces per thread (host guarantees the fit)
     constexpr int WPT = (9 * NT * 64 + 255) / 256; // weight half8 per thread
     const int n_pe = PR * PW * 4;
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
         pr -= (pr * PW > pix) ? 1 : 0;
         pr += ((pr + 1) * PW <= pix) ? 1 : 0;
         const int pc = pix - pr * PW;
-        const int iy = iy_base + pr, ix = pc - 1;
+        const int iy = iy_base + pr, ix = ix_base + pc;
         val_p[i] = use_p[i] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
         src_p[i] = a.s0.p + ((size_t)(img * a.Hin + (val_p[i] ? iy : 0)) * a.Win + (val_p[i] ? ix : 0)) * a.s0.ld + q * 8;
         dst_p[i] = pix * kPixStride + q * 16;
@@ -419,47 +444,71 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
     }
 }
 
-// LDS bytes / eligibility of the LDS kernel for a layer; 0 = not eligible
-size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max)
+// Geometry of the LDS kernel for one layer and tile shape.  The 2-D block scheme is used when the
+// block tiles the image exactly (no masked lanes); otherwise the row-run scheme.  bytes == 0: not eligible.
+struct LdsGeom { bool tile2d; int tiles_x, tiles_y, twc_log2, patch_bytes; size_t bytes; };
+
+static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt)
 {
-    if (a.Cin % 32 != 0 || a.s1.C != 0 || a.s0.shift != 0) return 0;
-    if (!((nt == 1) || ((nt == 2 || nt == 4) && a.pair))) return 0;
-    if (a.cout_pad % (16 * nt) != 0) return 0;
-    const int tpx = 64 * mt;
-    const int rows = (tpx + a.Wout - 2) / a.Wout + 1;          // most output rows a run of tpx pixels can touch
-    const int pr = (rows - 1) * stride + 3;
-    const int pw = a.Win + 2;
-    if ((size_t)pr * pw * 4 > 12 * 256) return 0;               // staging plan: at most 12 pieces per thread
-    if (stride == 2 && (size_t)pr * pw * kPixStride > 48 * 1024) return 0;   // wide stride-2 patches: the direct kernel measured faster
-    const size_t bytes = (size_t)pr * pw * kPixStride + (size_t)9 * nt * 1024;
-    if (bytes > 80 * 1024) return 0;                            // two workgroups per CU (one per CU measured slower than the direct kernel)
-    *patch_rows_max = pr;
-    return bytes;
+    LdsGeom g{false, 0, 0, 0, 0, 0};
+    if (a.Cin % 32 != 0 || a.s1.C != 0 || a.s0.shift != 0) return g;
+    if (!((nt == 1) || ((nt == 2 || nt == 4) && a.pair))) return g;
+    if (a.cout_pad % (16 * nt) != 0) return g;
+    if (stride == 2 && a.Hout * a.Wout > 400) return g;        // large stride-2 layers: the direct kernel measured as fast or faster
+    int pr, pw;
+    const int l2 = a.Wout % 16 == 0 ? 4 : (a.Wout % 8 == 0 ? 3 : (a.Wout % 4 == 0 ? 2 : -1));
+    const int rh = l2 >= 0 ? 4 * mt * (16 >> l2) : 0;
+    if (l2 >= 0 && a.Hout % rh == 0) {
+        g.tile2d = true;
+        g.twc_log2 = l2;
+        g.tiles_x = a.Wout >> l2;
+        g.tiles_y = a.Hout / rh;
+        pr = rh * stride + 2;
+        pw = (1 << l2) * stride + 2;
+    } else {
+        const int tpx = 64 * mt;
+        g.tiles_x = (a.Hout * a.Wout + tpx - 1) / tpx;
+        g.tiles_y = 1;
+        const int rows = (tpx + a.Wout - 2) / a.Wout + 1;      // most output rows a run of tpx pixels can touch
+        pr = (rows - 1) * stride + 3;
+        pw = a.Win + 2;
+    }
+    if ((size_t)pr * pw * 4 > 12 * 256) return g;               // staging plan: at most 12 pieces per thread
+    g.patch_bytes = pr * pw * kPixStride;
+    const size_t bytes = (size_t)g.patch_bytes + (size_t)9 * nt * 1024;
+    if (bytes > 80 * 1024) return g;                            // two or more workgroups per CU
+    g.bytes = bytes;
+    return g;
 }
 
-template <int STRIDE, int MT, int NT>
-static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, size_t lds, int pr, hipStream_t s)
+size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max)
 {
-    const int HWo = a.Hout * a.Wout;
-    const int tiles = (HWo + 64 * MT - 1) / (64 * MT);
+    const LdsGeom g = lds_geom(a, stride, mt, nt);
+    if (patch_rows_max) *patch_rows_max = g.patch_bytes;
+    return g.bytes;
+}
+
+template <int STRIDE, int MT, int NT, bool TILE2D>
+static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, const LdsGeom &g, hipStream_t s)
+{
     static bool attr_set = false;   // one flag per instantiation
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT>), dim3(tiles * batch, a.cout_pad / (16 * NT)), dim3(256), lds, s, a, wl,
-                       tiles, pr);
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D>), dim3(g.tiles_x * g.tiles_y * batch, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
+                       wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes);
 }
 
 bool launch_conv_lds(int stride, int mt, int nt, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s)
 {
-    int pr = 0;
-    const size_t lds = conv_lds_bytes(a, stride, mt, nt, &pr);
-    if (!lds) return false;
-#define IRMV_LDS(ST_, MT_, NT_)                                                   \
-    if (stride == ST_ && mt == MT_ && nt == NT_) {                                \
-        launch_lds_inst<ST_, MT_, NT_>(a, wl, batch, lds, pr, s);                 \
-        return true;                                                              \
+    const LdsGeom g = lds_geom(a, stride, mt, nt);
+    if (!g.bytes) return false;
+#define IRMV_LDS(ST_, MT_, NT_)                                                                \
+    if (stride == ST_ && mt == MT_ && nt == NT_) {                                             \
+        if (g.tile2d) launch_lds_inst<ST_, MT_, NT_, true>(a, wl, batch, g, s);                \
+        else launch_lds_inst<ST_, MT_, NT_, false>(a, wl, batch, g, s);                        \
+        return true;                                                                           \
     }
     IRMV_LDS(1, 1, 1) IRMV_LDS(1, 2, 1) IRMV_LDS(1, 4, 1)
     IRMV_LDS(1, 1, 2) IRMV_LDS(1, 2, 2) IRMV_LDS(1, 4, 2) IRMV_LDS(1, 1, 4) IRMV_LDS(1, 2, 4) IRMV_LDS(1, 4, 4)
