@@ -30,7 +30,7 @@ extern "C" {
 #define IRMV_ERR_ARG (-1)      /* bad argument / configuration            */
 #define IRMV_ERR_HIP (-2)      /* HIP runtime failure (message has detail) */
 #define IRMV_ERR_MODEL (-3)    /* weight blob missing or not matching      */
-#define IRMV_ERR_OVERFLOW (-4) /* more candidates than the device list holds */
+#define IRMV_ERR_OVERFLOW (-4) /* reserved (the candidate list now holds every (anchor, class) pair) */
 
 #define IRMV_RESIZE_STRETCH 0   /* reference behaviour: src/yolo_engine.cpp:186-190 */
 #define IRMV_RESIZE_LETTERBOX 1 /* north-star variant */
@@ -40,7 +40,7 @@ extern "C" {
 
 #define IRMV_NUM_CLASSES 14   /* ArmorClass B1..RS; 14 = UNKNOWN (include/irmv_detection/armor.hpp:7) */
 #define IRMV_MAX_DET_CAP 256
-#define IRMV_CAND_CAP 8192    /* (anchor, class) pairs kept per frame before NMS */
+#define IRMV_CAND_CAP 8192    /* most candidates the NMS walk can take (upper bound of pre_nms_cap) */
 
 typedef struct irmv_engine irmv_engine;
 

@@ -517,7 +517,7 @@ static int build_engine(irmv_engine *e)
 
     // ---- post-processing buffers ----
     TRY(dev_alloc(e, (void **)&e->boxes, (size_t)S * e->A * 16));
-    TRY(dev_alloc(e, (void **)&e->keys, (size_t)S * kCandCap * 8));
+    TRY(dev_alloc(e, (void **)&e->keys, (size_t)S * e->A * e->nc * 8));
     TRY(dev_alloc(e, (void **)&e->counts, (size_t)S * kCountStride * 4));
     HIP_TRY(hipMemset(e->counts, 0, (size_t)S * kCountStride * 4));
     TRY(dev_alloc(e, (void **)&e->dets_dev, (size_t)S * c.max_det * sizeof(DevDet)));
@@ -868,7 +868,8 @@ static PostArgs post_args(const irmv_engine *e, int first)
     p.slots_total = e->cfg.num_slots;
     p.first = first;
     p.boxes = e->boxes + (size_t)first * e->A * 4;
-    p.keys = e->keys + (size_t)first * kCandCap;
+    p.keys = e->keys + (size_t)first * e->A * e->nc;
+    p.key_cap = e->A * e->nc;
     p.counts = e->counts + (size_t)first * kCountStride;
     p.dets = e->dets_dev + (size_t)first * e->cfg.max_det;
     p.fout = e->fout_dev + first;

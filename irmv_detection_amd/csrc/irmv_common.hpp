@@ -103,7 +103,8 @@ struct PostArgs {
     const float *head_all;    // one allocation: [level][slot (all num_slots)][H*W][kHeadRec]
     int slots_total, first;   // level block offset = lvl_base * slots_total records; this step starts at slot `first`
     float *boxes;             // [B][A][4]
-    unsigned long long *keys; // [B][kCandCap]
+    unsigned long long *keys; // [B][key_cap]: every (anchor, class) pair above threshold, unsorted
+    int key_cap;              // = A * nc: the list can never overflow
     int *counts;              // [B][kCountStride]
     DevDet *dets;             // [B][max_det]
     DevFrameOut *fout;        // [B]

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
         const float logit = cl[i];
         if (c < a.nc && logit > a.logit_thr) {
             const int idx = atomicAdd(&a.counts[b * kCountStride], 1);
-            if (idx < kCandCap)
-                a.keys[(size_t)b * kCandCap + idx] =
+            if (idx < a.key_cap)
+                a.keys[(size_t)b * a.key_cap + idx] =
                     ((unsigned long long)orderable(logit) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(an * a.nc + c));
         }
     }
@@ -420,10 +420,53 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
 #define IRMV_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[b * 8 + (k)] = clock64(); } while (0)
     IRMV_STAMP(0);
     const int n_total = a.counts[b * kCountStride];
-    const int n_stored = n_total < kCandCap ? n_total : kCandCap;
-    const unsigned long long *gk = a.keys + (size_t)b * kCandCap;
+    const unsigned long long *gk = a.keys + (size_t)b * a.key_cap;
     const unsigned long long *sorted;
     if (tid < 16) cls_cnt[tid] = 0;
+    int n_stored = n_total;
+    bool preloaded = false;
+    if (n_total > kCandCap) {
+        // More candidates than the LDS sort holds (noise frames): keep exactly the K = pre_nms_cap largest
+        // keys.  Keys are unique, so an 8-pass MSB-first radix select finds the K-th largest key T exactly;
+        // every key >= T is then compacted into LDS.  Same result as sorting everything and cutting at K.
+        __shared__ unsigned int hist[256];
+        __shared__ int s_digit, s_rem, s_fill;
+        const int K = a.pre_nms_cap < kCandCap ? a.pre_nms_cap : kCandCap;
+        unsigned long long prefix = 0ull, mask = 0ull;
+        if (tid == 0) { s_rem = K; s_fill = 0; }
+        for (int pass = 0; pass < 8; pass++) {
+            const int shift = 56 - 8 * pass;
+            if (tid < 256) hist[tid] = 0u;
+            __syncthreads();
+            for (int i = tid; i < n_total; i += blockDim.x) {
+                const unsigned long long key = gk[i];
+                if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int rem = s_rem, d = 255;
+                for (; d > 0; d--) {
+                    if ((int)hist[d] >= rem) break;
+                    rem -= (int)hist[d];
+                }
+                s_digit = d;
+                s_rem = rem;
+            }
+            __syncthreads();
+            prefix |= (unsigned long long)s_digit << shift;
+            mask |= 0xffull << shift;
+        }
+        for (int i = tid; i < n_total; i += blockDim.x) {
+            const unsigned long long key = gk[i];
+            if (key >= prefix) {
+                const int pos = atomicAdd(&s_fill, 1);
+                if (pos < kCandCap) skeys[pos] = key;
+            }
+        }
+        __syncthreads();
+        n_stored = s_fill < kCandCap ? s_fill : kCandCap;
+        preloaded = true;
+    }
 
     if (n_stored <= kRankSortUse) {
         for (int i = tid; i < n_stored; i += blockDim.x) skeys[i] = gk[i];
@@ -450,7 +493,9 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     } else {
         int npow = 512;
         while (npow < n_stored) npow <<= 1;
-        for (int i = tid; i < npow; i += blockDim.x) skeys[i] = i < n_stored ? gk[i] : 0ull;
+        if (!preloaded)
+            for (int i = tid; i < n_stored; i += blockDim.x) skeys[i] = gk[i];
+        for (int i = n_stored + tid; i < npow; i += blockDim.x) skeys[i] = 0ull;
         __syncthreads();
         for (int k = 2; k <= npow; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -542,7 +587,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         DevFrameOut fo;
         fo.num_dets = kept;
         fo.n_candidates = n_total;
-        fo.overflow = n_total > kCandCap ? 1 : 0;
+        fo.overflow = 0;   // (the candidate list is sized for every (anchor, class) pair; kept for ABI stability)
         fo.pad = 0;
         a.fout[b] = fo;
     }

@@ -51,8 +51,7 @@ def test_preprocess_bit_exact(blob, size, mode, rot, swap):
     img = rng.integers(0, 256, (size[1], size[0], 3), dtype=np.uint8)
     with YoloEngine(None, size, weights_blob=blob, resize_mode=mode, rotate180=rot, swap_rb=swap) as e:
         _load(e, 0, img)
-        e.submit(0, 1)          # (noise frames can overflow the candidate list; only the input is checked here)
-        e.wait()
+        e.detect()
         got = e.read_input(0)
     exp = oracle.preprocess(img, 640, mode, rot, swap).astype(np.float16).astype(np.float32)
     assert np.array_equal(got, exp)
@@ -179,14 +178,18 @@ def test_post_max_det_and_thresholds(blob):
         assert raw["num_dets"] == 17
 
 
-def test_candidate_overflow_is_reported_not_hidden(eng):
+def test_more_candidates_than_the_lds_sort_holds(eng):
+    """> 8192 (anchor, class) pairs above threshold: the kernel radix-selects exactly the pre_nms_cap best
+    keys before sorting -- same survivors as the oracle's sort-everything-then-cut."""
     head = np.zeros((8400, 86), np.float32)
-    head[:, 64:78] = 3.0                                # 117 600 pairs above threshold > IRMV_CAND_CAP
-    eng.write_head(head, 0)
-    eng.run_post(0, 1)
-    with pytest.raises(capi.IrmvError) as ei:
-        eng.results(0)
-    assert ei.value.code == capi.ERR_OVERFLOW
+    head[:, 64:78] = 3.0                                # all 117 600 pairs pass, all tied: order = anchor, then class
+    raw = _assert_post_exact(eng, head)
+    assert raw["n_candidates"] == 8400 * 14 and raw["num_dets"] > 0
+    rng = np.random.default_rng(21)
+    head = _synthetic_head(rng, 0.15)                   # ~17 000 distinct scores
+    raw = _assert_post_exact(eng, head)
+    assert raw["n_candidates"] > capi.CAND_CAP
+    eng.results(0)                                      # no overflow error any more
 
 
 # ---------------------------------------------------------------- end to end / API
