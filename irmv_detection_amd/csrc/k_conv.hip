@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                     }
                     if (ACT == 1) {
 #pragma unroll
-                        for (int i = 0; i < 8; i++) vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
+                        for (int i = 0; i < 8; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
                     }
                     if (a.res) {
                         const half8 rv = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + c0);
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             for (int i = 0; i < 4; i++) vals[i] = acc[mt][nt][i] + a.bias[c0 + i];
             if (ACT == 1) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
+                for (int i = 0; i < 4; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
             }
             if constexpr (OUT_F32) {
                 *reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + m * a.out_ld + c0) =
@@ -331,6 +331,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
     for (int i = 0; i < PMAX; i++) {
         const int e = tid + i * 256;
         use_p[i] = e < n_pe;
+        val_p[i] = false;
+        src_p[i] = a.s0.p;
+        dst_p[i] = 0;
+        if (i * 256 >= n_pe) continue;                     // wave-uniform: this piece slot is unused by the whole workgroup
         const int pix = use_p[i] ? (e >> 2) : 0, q = e & 3;
         int pr = (int)((float)pix * inv_pw);               // pix < 2^16: one correction step makes the quotient exact
         pr -= (pr * PW > pix) ? 1 : 0;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
                     vals[4 + i] = acc[mt][2 * u + 1][i] + a.bias[c0 + 4 + i];
                 }
 #pragma unroll
-                for (int i = 0; i < 8; i++) vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
+                for (int i = 0; i < 8; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
                 if (a.res) {
                     const half8 rv = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + c0);
 #pragma unroll
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 vals[i] = acc[mt][0][i] + a.bias[c0 + i];
-                vals[i] = vals[i] * __frcp_rn(1.0f + __expf(-vals[i]));
+                vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
             }
             if (a.res) {
                 const half4 rv = *reinterpret_cast<const half4 *>(a.res + m * a.res_ld + c0);

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const float v = acc[i] + a.b[g * 4 + i];
-                o[i] = (half_t)(v * __frcp_rn(1.0f + __expf(-v)));
+                o[i] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
             }
             *reinterpret_cast<half4 *>(a.y + (size_t)mm * 16 + g * 4) = o;
         }
