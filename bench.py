@@ -92,8 +92,9 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_idx = D.device_index(local_rank)
+    torch.cuda.set_device(dev_idx)
+    dev = torch.device("cuda", dev_idx)
     sw, sh = (int(v) for v in args.src.lower().split("x"))
     B = args.frames_per_step
 
@@ -101,7 +102,7 @@ def main():
     blob = weights.synthetic_blob(0) if rank == 0 else None
     wt = D.broadcast_blob(blob, dev)
     torch.cuda.synchronize()
-    eng = YoloEngine(None, (sw, sh), device=local_rank, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(),
+    eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(),
                      num_slots=B)
 
     # this rank's frames: round-robin over the global frame index, made resident in HBM once
@@ -166,7 +167,9 @@ def main():
     dbg("profile")
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the engine's stream ----
-        prof_runs = [eng.profile(0, B) for _ in range(5)][1:]
+        # each captured graph of the timed region carries this many frames (a step is cut into num_streams sub-batches)
+        per_graph = (B + eng.num_streams - 1) // eng.num_streams
+        prof_runs = [eng.profile(0, per_graph) for _ in range(5)][1:]
         agg = {}
         for run in prof_runs:
             for st in run:
@@ -201,8 +204,8 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"synthetic {sw}x{sh} u8 camera frames resident in HBM -> 640x640 YOLOv8n "
                                    f"(nc=14, 4-kpt head, seeded weights) -> decode+NMS -> IPPE PnP; "
-                                   f"{B} independent frames per hipGraph step per GPU (BASELINE configs[1]/[2])",
-                       "frames_per_step_per_gpu": B, "src": f"{sw}x{sh}", "net": 640, "parallelism": f"dp{world} (replicas, frames sharded)",
+                                   f"{B} independent frames per step per GPU as {eng.num_streams} concurrently replayed hipGraphs (BASELINE configs[1]/[2])",
+                       "frames_per_step_per_gpu": B, "streams_per_gpu": eng.num_streams, "src": f"{sw}x{sh}", "net": 640, "parallelism": f"dp{world} (replicas, frames sharded)",
                        "gflop_per_frame": round(arch.flops_per_frame() / 1e9, 3), "detections_last_step_rank0": n_dets},
             "roofline": roofline,
         }

@@ -68,7 +68,8 @@ typedef struct irmv_engine_cfg {
     const void *weights_blob;  /* .irmw image in host memory, or in device memory if weights_on_device */
     uint64_t weights_bytes;
     int32_t weights_on_device; /* 1: weights_blob is a device pointer (e.g. filled by an RCCL broadcast) */
-    int32_t reserved;
+    int32_t num_streams;       /* HIP streams a multi-slot submit() is spread over (0 = default 2); independent
+                                  sub-batches on separate streams fill each other's launch gaps and tails */
 } irmv_engine_cfg;
 
 /* One detection: YoloEngine::bbox (yolo_engine.hpp:19-26) in source-frame
@@ -119,6 +120,7 @@ int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out);
 void irmv_engine_destroy(irmv_engine *e);
 int irmv_engine_num_slots(const irmv_engine *e);
 int irmv_engine_max_det(const irmv_engine *e);
+int irmv_engine_num_streams(const irmv_engine *e);
 
 /* Pinned host frame slot (src_height*src_width*3 bytes, HWC u8), valid for the
  * engine's lifetime; producer threads write straight into it -- the counterpart

@@ -35,7 +35,7 @@ class EngineCfg(C.Structure):
         ("armor_size", C.c_int32),
         ("camera_matrix", C.c_double * 9), ("dist_coeffs", C.c_double * 5),
         ("weights_path", C.c_char_p), ("weights_blob", C.c_void_p), ("weights_bytes", C.c_uint64),
-        ("weights_on_device", C.c_int32), ("reserved", C.c_int32),
+        ("weights_on_device", C.c_int32), ("num_streams", C.c_int32),
     ]
 
 
@@ -72,6 +72,7 @@ SYMBOLS = [
     ("irmv_engine_destroy", None, [_P]),
     ("irmv_engine_num_slots", C.c_int, [_P]),
     ("irmv_engine_max_det", C.c_int, [_P]),
+    ("irmv_engine_num_streams", C.c_int, [_P]),
     ("irmv_engine_src_buffer", C.POINTER(C.c_uint8), [_P, C.c_int]),
     ("irmv_engine_src_device_buffer", C.c_void_p, [_P, C.c_int]),
     ("irmv_engine_submit", C.c_int, [_P, C.c_int, C.c_int, C.c_uint32]),

@@ -21,15 +21,22 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def device_index(local_rank: int) -> int:
+    """HIP device of this rank: LOCAL_RANK, unless IRMV_FORCE_DEVICE pins every rank to one card (rehearsal)."""
+    forced = os.environ.get("IRMV_FORCE_DEVICE")
+    return int(forced) if forced is not None else local_rank
+
+
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # IRMV_DIST_BACKEND=gloo: rehearse the N > 1 path with several ranks on ONE GPU (RCCL refuses that)
+            backend = os.environ.get("IRMV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(device_index(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 

@@ -94,7 +94,7 @@ class YoloEngine:
                  iou_thr: float = 0.45, max_det: int = 100, pre_nms_cap: int = 4096,
                  camera_matrix: Sequence[float] = DEFAULT_CAMERA_MATRIX,
                  dist_coeffs: Sequence[float] = DEFAULT_DIST_COEFFS, armor_size: int = capi.ARMOR_SMALL,
-                 warmup: int = 0):
+                 num_streams: int = 0, warmup: int = 0):
         L = capi.load()
         cfg = capi.EngineCfg()
         L.irmv_engine_cfg_default(C.byref(cfg))
@@ -104,6 +104,7 @@ class YoloEngine:
         cfg.resize_mode, cfg.rotate180, cfg.swap_rb = resize_mode, int(rotate180), int(swap_rb)
         cfg.score_thr, cfg.iou_thr, cfg.max_det, cfg.pre_nms_cap = score_thr, iou_thr, max_det, pre_nms_cap
         cfg.num_slots, cfg.armor_size = num_slots, armor_size
+        cfg.num_streams = num_streams
         cfg.camera_matrix = (C.c_double * 9)(*camera_matrix)
         cfg.dist_coeffs = (C.c_double * 5)(*(list(dist_coeffs) + [0.0] * 5)[:5])
         self._blob_keepalive = None
@@ -128,6 +129,7 @@ class YoloEngine:
         self.slot = slot
         self.max_det = max_det
         self.enable_profiling = enable_profiling
+        self.num_streams = L.irmv_engine_num_streams(self._h)
         self.num_anchors = L.irmv_engine_num_anchors(self._h)
         self.head_channels = L.irmv_engine_head_channels(self._h)
         self._dets = (capi.Det * max_det)()

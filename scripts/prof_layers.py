@@ -6,7 +6,7 @@ import numpy as np
 from irmv_detection_amd import frames, weights
 from irmv_detection_amd.engine import YoloEngine
 B = int(os.environ.get("SLOTS", "16"))
-eng = YoloEngine(None, (1280, 1024), weights_blob=weights.synthetic_blob(0), num_slots=B)
+eng = YoloEngine(None, (1280, 1024), weights_blob=weights.synthetic_blob(0), num_slots=B, num_streams=int(os.environ.get('STREAMS', '1')))
 for s in range(B):
     eng.get_src_image_buffer(s)[:] = frames.synthetic_frame(s)
 eng.submit(0, B); eng.wait()
