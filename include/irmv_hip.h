@@ -38,6 +38,10 @@ extern "C" {
 #define IRMV_ARMOR_SMALL 0 /* 135 x 55 mm; the reference always solves with this one (src/pnp_solver.cpp:47) */
 #define IRMV_ARMOR_LARGE 1 /* 225 x 55 mm */
 
+#define IRMV_POINTS_AUTO 0
+#define IRMV_POINTS_KEYPOINT_HEAD 1
+#define IRMV_POINTS_CLASSICAL 2 /* gray -> threshold -> contours -> minAreaRect -> lights, on the GPU */
+
 #define IRMV_NUM_CLASSES 14   /* ArmorClass B1..RS; 14 = UNKNOWN (include/irmv_detection/armor.hpp:7) */
 #define IRMV_MAX_DET_CAP 256
 #define IRMV_CAND_CAP 8192    /* most candidates the NMS walk can take (upper bound of pre_nms_cap) */
@@ -70,6 +74,19 @@ typedef struct irmv_engine_cfg {
     int32_t weights_on_device; /* 1: weights_blob is a device pointer (e.g. filled by an RCCL broadcast) */
     int32_t num_streams;       /* HIP streams a multi-slot submit() is spread over (0 = default 2); independent
                                   sub-batches on separate streams fill each other's launch gaps and tails */
+    /* Source of the four armor points PnP consumes.  The reference obtains them by classical CV inside
+     * each bbox (IrmDetector::extract_armors, src/irm_detector.cpp:292-355); a pose-style model carries them
+     * in a keypoint head.  IRMV_POINTS_AUTO picks the keypoint head when the model has one. */
+    int32_t point_source;      /* IRMV_POINTS_* */
+    int32_t binary_threshold;  /* 150 (src/irm_detector.cpp:152) */
+    float light_min_ratio;     /* 0.1 */
+    float light_max_ratio;     /* 0.4 */
+    float light_max_angle;     /* 40 degrees */
+    float reserved0;
+    double armor_min_small_center_distance; /* 0.8 */
+    double armor_max_small_center_distance; /* 3.2 */
+    double armor_min_large_center_distance; /* 3.2 */
+    double armor_max_large_center_distance; /* 5.5 */
 } irmv_engine_cfg;
 
 /* One detection: YoloEngine::bbox (yolo_engine.hpp:19-26) in source-frame
@@ -87,6 +104,13 @@ typedef struct irmv_det {
     double rvec[3];
     double tvec[3];
     double quat[4];    /* x, y, z, w */
+    int32_t armor_valid; /* 1: kpts are an armor's points (keypoint head: always; classical: two gated lights found);
+                            0: no armor in this bbox; -1: no answer, the extraction scratch was exhausted (the frame's
+                            bboxes cover more than 8 frame areas in total, or one bbox holds more than 1024 contours /
+                            4096 contour points) -- reported, never replaced by a truncated result */
+    int32_t armor_size;  /* IRMV_ARMOR_*: classical path derives it from the light-centre distance (src/irm_detector.cpp:340-341) */
+    int32_t n_lights;    /* classical path: lights that passed is_light() in this bbox */
+    int32_t reserved;
 } irmv_det;
 
 /* EfficientNMS-layout view of one frame's result in net-input coordinates
@@ -149,6 +173,11 @@ double irmv_engine_last_detect_ms(const irmv_engine *e);
 /* 180-degree rotated frame of a slot (what get_rotated_image() aliases after the
  * in-place mirror, src/yolo_engine.cpp:77-78,182-184), rotated on the GPU. */
 int irmv_engine_rotated_image(irmv_engine *e, int slot, uint8_t *dst_hwc);
+
+/* IrmDetector::extract_armors(get_rotated_image(), bboxes) (src/irm_detector.cpp:183,292-355) on the GPU:
+ * for each of the n boxes (xyxy, rotated-frame pixels) on the slot's current frame -> out[i].kpts (LB, LT, RT,
+ * RB), armor_valid, armor_size, n_lights, and the PnP pose.  Works for any model / point_source. */
+int irmv_engine_extract_armors(irmv_engine *e, int slot, const float *xyxy, int n, irmv_det *out);
 
 /* ---- stage-wise read-backs used by the parity tests -------------------- */
 int irmv_engine_read_input(irmv_engine *e, int slot, float *chw);             /* [3][net][net], as the reference's input_buffer_ */

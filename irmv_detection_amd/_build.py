@@ -20,6 +20,7 @@ SOURCES = [
     ("k_pre.hip", []),
     ("k_conv.hip", []),
     ("k_post.hip", ["-ffp-contract=off"]),
+    ("k_light.hip", ["-ffp-contract=off"]),
     ("engine.cpp", ["-x", "hip"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
@@ -42,7 +43,7 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "irmv_common.hpp"), os.path.join(INCLUDE, "irmv_hip.h"), __file__]
+    headers = [os.path.join(CSRC, "irmv_common.hpp"), os.path.join(CSRC, "pnp_device.hpp"), os.path.join(INCLUDE, "irmv_hip.h"), __file__]
     objs = []
     cc = hipcc()
     for src, extra in SOURCES:

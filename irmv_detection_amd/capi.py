@@ -14,6 +14,7 @@ OK, ERR_ARG, ERR_HIP, ERR_MODEL, ERR_OVERFLOW = 0, -1, -2, -3, -4
 RESIZE_STRETCH, RESIZE_LETTERBOX = 0, 1
 ARMOR_SMALL, ARMOR_LARGE = 0, 1
 SUBMIT_H2D = 1
+POINTS_AUTO, POINTS_KEYPOINT_HEAD, POINTS_CLASSICAL = 0, 1, 2
 NUM_CLASSES = 14
 MAX_DET_CAP = 256
 CAND_CAP = 8192
@@ -36,6 +37,10 @@ class EngineCfg(C.Structure):
         ("camera_matrix", C.c_double * 9), ("dist_coeffs", C.c_double * 5),
         ("weights_path", C.c_char_p), ("weights_blob", C.c_void_p), ("weights_bytes", C.c_uint64),
         ("weights_on_device", C.c_int32), ("num_streams", C.c_int32),
+        ("point_source", C.c_int32), ("binary_threshold", C.c_int32),
+        ("light_min_ratio", C.c_float), ("light_max_ratio", C.c_float), ("light_max_angle", C.c_float), ("reserved0", C.c_float),
+        ("armor_min_small_center_distance", C.c_double), ("armor_max_small_center_distance", C.c_double),
+        ("armor_min_large_center_distance", C.c_double), ("armor_max_large_center_distance", C.c_double),
     ]
 
 
@@ -44,6 +49,7 @@ class Det(C.Structure):
         ("xyxy", C.c_float * 4), ("score", C.c_float), ("class_id", C.c_int32),
         ("anchor", C.c_int32), ("pnp_ok", C.c_int32), ("kpts", C.c_float * 8),
         ("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("quat", C.c_double * 4),
+        ("armor_valid", C.c_int32), ("armor_size", C.c_int32), ("n_lights", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -81,6 +87,7 @@ SYMBOLS = [
     ("irmv_engine_detect", C.c_int, [_P, C.c_int, C.POINTER(Det), C.c_int, C.POINTER(C.c_int)]),
     ("irmv_engine_last_detect_ms", C.c_double, [_P]),
     ("irmv_engine_rotated_image", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint8)]),
+    ("irmv_engine_extract_armors", C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(Det)]),
     ("irmv_engine_read_input", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     ("irmv_engine_read_head", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     ("irmv_engine_write_head", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),

@@ -32,6 +32,8 @@
 
 using namespace irmv;
 
+constexpr int kLightPointsCap = 4096;       // contour points per detection
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg)
 {
@@ -98,7 +100,7 @@ struct Tensor {
 
 struct SegRef { int t = -1, coff = 0, C = 0, shift = 0; };
 
-enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_DECODE, OP_NMS };
+enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_DECODE, OP_NMS, OP_LIGHT };
 
 struct Op {
     OpKind kind;
@@ -152,6 +154,12 @@ struct irmv_engine {
     float *head_all = nullptr;
     PnpConst *pnp_dev = nullptr;
     long long *dbg_dev = nullptr;
+    bool classical = false;            // four points from the classical light extraction instead of a keypoint head
+    signed char *light_labels = nullptr;   // label pool: light_pool bytes per slot
+    size_t light_pool = 0;
+    short *light_points = nullptr, *light_hulls = nullptr;
+    float *light_boxes = nullptr;      // explicit boxes of irmv_engine_extract_armors
+    DevDet *light_dets_dev = nullptr, *light_dets_host = nullptr;
     float *boxes = nullptr;
     unsigned long long *keys = nullptr;
     int *counts = nullptr;
@@ -184,6 +192,7 @@ irmv_engine::~irmv_engine()
     if (src_host) (void)hipHostFree(src_host);
     if (dets_host) (void)hipHostFree(dets_host);
     if (fout_host) (void)hipHostFree(fout_host);
+    if (light_dets_host) (void)hipHostFree(light_dets_host);
     for (int i = 0; i < 7; i++)
         if (extra_streams[i]) { (void)hipStreamSynchronize(extra_streams[i]); (void)hipStreamDestroy(extra_streams[i]); }
     for (int i = 0; i < 3; i++) {
@@ -542,6 +551,21 @@ static int build_engine(irmv_engine *e)
     { Op op; op.kind = OP_DECODE; op.layer = "decode"; snprintf(op.kname, sizeof op.kname, "decode");
       op.bytes = (double)e->A * (kHeadRec * 4 + 16); e->ops.push_back(op); }
     { Op op; op.kind = OP_NMS; op.layer = "nms_kpt_pnp"; snprintf(op.kname, sizeof op.kname, "nms_pnp"); e->ops.push_back(op); }
+    if (c.point_source == IRMV_POINTS_KEYPOINT_HEAD && e->nk < 8) return fail(IRMV_ERR_MODEL, "point_source = keypoint head, but the model has none");
+    e->classical = c.point_source == IRMV_POINTS_CLASSICAL || (c.point_source == IRMV_POINTS_AUTO && e->nk < 8);
+    if (e->classical) {
+        Op op; op.kind = OP_LIGHT; op.layer = "extract_armors"; snprintf(op.kname, sizeof op.kname, "light_extract");
+        e->ops.push_back(op);
+    }
+    // scratch of the classical extraction: per detection a padded label image (ROIs up to ~510 x 510) and contour points
+    const size_t SL = e->classical ? (size_t)S : 1;   // keypoint mode keeps one slot's worth for irmv_engine_extract_armors
+    e->light_pool = std::max<size_t>((size_t)8 * c.src_width * c.src_height, (size_t)(c.src_width + 2) * (c.src_height + 2) + 16);
+    TRY(dev_alloc(e, (void **)&e->light_labels, SL * e->light_pool));
+    TRY(dev_alloc(e, (void **)&e->light_points, SL * c.max_det * kLightPointsCap * 2 * sizeof(short)));
+    TRY(dev_alloc(e, (void **)&e->light_hulls, SL * c.max_det * kLightPointsCap * 4 * sizeof(short)));
+    TRY(dev_alloc(e, (void **)&e->light_boxes, (size_t)c.max_det * 16));
+    TRY(dev_alloc(e, (void **)&e->light_dets_dev, (size_t)c.max_det * sizeof(DevDet)));
+    HIP_TRY(hipHostMalloc((void **)&e->light_dets_host, (size_t)c.max_det * sizeof(DevDet), hipHostMallocDefault));
 
     PostArgs &p = e->post;
     p.net = net; p.A = e->A; p.nc = e->nc; p.nk = e->nk;
@@ -658,6 +682,12 @@ extern "C" void irmv_engine_cfg_default(irmv_engine_cfg *cfg)
     const double D[5] = {-0.405274, 0.126058, -0.026939, -0.006503, 0.0};
     memcpy(cfg->camera_matrix, K, sizeof K);
     memcpy(cfg->dist_coeffs, D, sizeof D);
+    // src/irm_detector.cpp:152-173
+    cfg->point_source = IRMV_POINTS_AUTO;
+    cfg->binary_threshold = 150;
+    cfg->light_min_ratio = 0.1f; cfg->light_max_ratio = 0.4f; cfg->light_max_angle = 40.0f;
+    cfg->armor_min_small_center_distance = 0.8; cfg->armor_max_small_center_distance = 3.2;
+    cfg->armor_min_large_center_distance = 3.2; cfg->armor_max_large_center_distance = 5.5;
 }
 
 extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
@@ -671,6 +701,7 @@ extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
     if (cfg->pre_nms_cap < 1 || cfg->pre_nms_cap > IRMV_CAND_CAP) return fail(IRMV_ERR_ARG, "pre_nms_cap must be 1..8192");
     if (!(cfg->score_thr > 0.f && cfg->score_thr < 1.f)) return fail(IRMV_ERR_ARG, "score_thr must be in (0, 1)");
     if (cfg->armor_size != IRMV_ARMOR_SMALL && cfg->armor_size != IRMV_ARMOR_LARGE) return fail(IRMV_ERR_ARG, "bad armor_size");
+    if (cfg->point_source < 0 || cfg->point_source > 2) return fail(IRMV_ERR_ARG, "bad point_source");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(IRMV_ERR_HIP, "no such HIP device");
@@ -873,6 +904,33 @@ static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int co
     a.pair = op.pair ? 1 : 0;
 }
 
+static LightArgs light_args(const irmv_engine *e, int first)
+{
+    LightArgs a{};
+    const irmv_engine_cfg &c = e->cfg;
+    a.frames = e->src_dev + (size_t)first * e->frame_bytes;
+    a.frame_bytes = e->frame_bytes;
+    a.cols = c.src_width; a.rows = c.src_height; a.rotate180 = c.rotate180;
+    a.dets = e->dets_dev + (size_t)first * c.max_det;
+    a.max_det = c.max_det;
+    a.num_dets = reinterpret_cast<const int *>(e->fout_dev + first);
+    a.num_dets_stride = (int)(sizeof(DevFrameOut) / sizeof(int));
+    a.n_boxes = 0;
+    a.boxes = nullptr;
+    a.labels = e->light_labels + (size_t)first * e->light_pool;
+    a.label_pool = e->light_pool;
+    a.points = e->light_points + (size_t)first * c.max_det * kLightPointsCap * 2;
+    a.points_cap = kLightPointsCap;
+    a.hulls = e->light_hulls + (size_t)first * c.max_det * kLightPointsCap * 4;
+    a.binary_threshold = c.binary_threshold;
+    a.light_min_ratio = c.light_min_ratio; a.light_max_ratio = c.light_max_ratio; a.light_max_angle = c.light_max_angle;
+    a.min_small_cd = c.armor_min_small_center_distance; a.max_small_cd = c.armor_max_small_center_distance;
+    a.min_large_cd = c.armor_min_large_center_distance; a.max_large_cd = c.armor_max_large_center_distance;
+    a.pnp = e->pnp_dev;
+    a.pnp_armor_size = c.armor_size;
+    return a;
+}
+
 static PostArgs post_args(const irmv_engine *e, int first)
 {
     PostArgs p = e->post;
@@ -902,7 +960,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     bool lane_used[3] = {false, false, false};
     int lane_level[3] = {-1, -1, -1};
     for (const Op &op : e->ops) {
-        if (post_only && op.kind != OP_DECODE && op.kind != OP_NMS) continue;
+        if (post_only && op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) continue;
         hipStream_t s = e->stream;
         if (fork && op.lane > 0) {
             const int ln = op.lane - 1;
@@ -926,7 +984,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             HIP_TRY(hipEventCreate(&r.b));
             HIP_TRY(hipEventRecord(r.a, s));
         }
-        const int reps = (ev && op.kind != OP_DECODE && op.kind != OP_NMS) ? (int)(flags & 0xffu) : 1;
+        const int reps = (ev && op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) ? (int)(flags & 0xffu) : 1;
         for (int rep = 0; rep < (reps > 0 ? reps : 1); rep++)
         switch (op.kind) {
         case OP_PRE: {
@@ -961,6 +1019,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         }
         case OP_DECODE: launch_decode(pa, count, s); break;
         case OP_NMS: launch_nms_pnp(pa, count, s); break;
+        case OP_LIGHT: launch_light_extract(light_args(e, first), e->cfg.max_det, count, s); break;
         }
         HIP_TRY(hipGetLastError());
         if (fork && op.signal >= 0) HIP_TRY(hipEventRecord(e->ev_level[op.signal], e->stream));
@@ -1077,6 +1136,10 @@ extern "C" int irmv_engine_results(irmv_engine *e, int slot, irmv_det *out, int 
         memcpy(o.rvec, d[i].rvec, 24);
         memcpy(o.tvec, d[i].tvec, 24);
         memcpy(o.quat, d[i].quat, 32);
+        o.armor_valid = d[i].armor_valid;
+        o.armor_size = d[i].armor_size;
+        o.n_lights = d[i].n_lights;
+        o.reserved = 0;
     }
     *n = k;
     if (fo.overflow) return fail(IRMV_ERR_OVERFLOW, "more than IRMV_CAND_CAP candidates above score_thr; raise score_thr");
@@ -1105,6 +1168,47 @@ extern "C" int irmv_engine_rotated_image(irmv_engine *e, int slot, uint8_t *dst)
     launch_rotate180(e->src_dev + (size_t)slot * e->frame_bytes, e->rot_dev, e->cfg.src_width, e->cfg.src_height, e->stream);
     HIP_TRY(hipMemcpyAsync(dst, e->rot_dev, e->frame_bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_extract_armors(irmv_engine *e, int slot, const float *xyxy, int n, irmv_det *out)
+{
+    TRY(check_range(e, slot, 1));
+    if (n < 0 || n > e->cfg.max_det || (n > 0 && (!xyxy || !out))) return fail(IRMV_ERR_ARG, "n must be 0..max_det with xyxy/out set");
+    if (n == 0) return IRMV_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    TRY(irmv_engine_wait(e));
+    hipStream_t st = e->stream;
+    HIP_TRY(hipMemcpyAsync(e->src_dev + (size_t)slot * e->frame_bytes, e->src_host + (size_t)slot * e->frame_bytes, e->frame_bytes,
+                           hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(e->light_boxes, xyxy, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    LightArgs a = light_args(e, slot);
+    a.dets = e->light_dets_dev;
+    a.labels = e->light_labels;
+    a.points = e->light_points;
+    a.hulls = e->light_hulls;
+    a.num_dets = nullptr;
+    a.n_boxes = n;
+    a.boxes = e->light_boxes;
+    launch_light_extract(a, n, 1, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->light_dets_host, e->light_dets_dev, (size_t)n * sizeof(DevDet), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < n; i++) {
+        const DevDet &d = e->light_dets_host[i];
+        irmv_det &o = out[i];
+        memset(&o, 0, sizeof o);
+        memcpy(o.xyxy, xyxy + 4 * i, 16);
+        o.class_id = IRMV_NUM_CLASSES;
+        o.pnp_ok = d.pnp_ok;
+        memcpy(o.kpts, d.kpts, 32);
+        memcpy(o.rvec, d.rvec, 24);
+        memcpy(o.tvec, d.tvec, 24);
+        memcpy(o.quat, d.quat, 32);
+        o.armor_valid = d.armor_valid;
+        o.armor_size = d.armor_size;
+        o.n_lights = d.n_lights;
+    }
     return IRMV_OK;
 }
 
@@ -1226,7 +1330,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
         (void)hipEventDestroy(ev[i].a);
         (void)hipEventDestroy(ev[i].b);
         const Op &op = e->ops[i];
-        if (op.kind != OP_DECODE && op.kind != OP_NMS) ms /= (float)kProfileRepeat;
+        if (op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) ms /= (float)kProfileRepeat;
         if (k < cap && stats) {
             irmv_kernel_stat &st = stats[k];
             memset(&st, 0, sizeof st);

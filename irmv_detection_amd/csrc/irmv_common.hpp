@@ -91,6 +91,10 @@ struct DevDet {           // device/pinned result record
     float kpts_net[8];
     float kpts[8];
     double rvec[3], tvec[3], quat[4];
+    int32_t armor_valid;  // 1: kpts hold an armor's four points; 0: none; -1: ROI larger than the label scratch
+    int32_t armor_size;   // 0 small / 1 large (classical path: from the light-centre distance)
+    int32_t n_lights;     // classical path: lights that passed the gates in this ROI
+    int32_t pad_;
 };
 struct DevFrameOut { int32_t num_dets, n_candidates, overflow, pad; };
 
@@ -119,6 +123,31 @@ struct PostArgs {
 };
 void launch_decode(const PostArgs &a, int batch, hipStream_t s);
 void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s);
+// ---- classical light extraction (k_light.hip) -------------
+constexpr int kLightMaxContours = 1024;   // contours per ROI; more -> armor_valid = -1 (no answer), never a truncated one
+
+struct LightArgs {
+    const uint8_t *frames;   // [B][rows][cols][3] device frames (un-rotated; rotation folded into the fetch)
+    size_t frame_bytes;
+    int cols, rows, rotate180;
+    DevDet *dets;            // [B][max_det]: xyxy in (bbox source when boxes == nullptr), armor fields out
+    int max_det;
+    const int *num_dets;     // per frame, stride num_dets_stride ints; nullptr -> n_boxes for every frame
+    int num_dets_stride, n_boxes;
+    const float *boxes;      // optional explicit boxes [n_boxes][4] (irmv_engine_extract_armors)
+    signed char *labels;     // [B][label_pool] per-frame pool the padded label images are carved from, in detection order
+    size_t label_pool;       // bytes per frame (>= one full-frame ROI)
+    short *points;           // [B][max_det][points_cap][2] contour points
+    int points_cap;
+    short *hulls;            // [B][max_det][points_cap * 2][2] hull scratch
+    int binary_threshold;
+    float light_min_ratio, light_max_ratio, light_max_angle;
+    double min_small_cd, max_small_cd, min_large_cd, max_large_cd;
+    const PnpConst *pnp;
+    int pnp_armor_size;
+};
+void launch_light_extract(const LightArgs &a, int n_boxes_max, int batch, hipStream_t s);
+
 void launch_pnp_only(const PnpConst &c, const float *pts, int n, int armor_size, double *rvec, double *tvec,
                      int32_t *ok, hipStream_t s);
 

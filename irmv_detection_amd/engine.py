@@ -60,6 +60,9 @@ class Armor:
     center: Tuple[float, float] = (0.0, 0.0)
     bbox_xyxy: Tuple[float, float, float, float] = (0.0, 0.0, 0.0, 0.0)
     pnp_ok: bool = False
+    valid: bool = True      # the four points exist (classical extraction found two gated lights / keypoint head)
+    n_lights: int = 0
+    no_answer: bool = False  # classical extraction ran out of scratch for this bbox (irmv_det.armor_valid == -1)
     rvec: Optional[np.ndarray] = None
     tvec: Optional[np.ndarray] = None
     quat_xyzw: Optional[np.ndarray] = None
@@ -94,7 +97,9 @@ class YoloEngine:
                  iou_thr: float = 0.45, max_det: int = 100, pre_nms_cap: int = 4096,
                  camera_matrix: Sequence[float] = DEFAULT_CAMERA_MATRIX,
                  dist_coeffs: Sequence[float] = DEFAULT_DIST_COEFFS, armor_size: int = capi.ARMOR_SMALL,
-                 num_streams: int = 0, warmup: int = 0):
+                 num_streams: int = 0, point_source: int = capi.POINTS_AUTO, binary_threshold: int = 150,
+                 light_min_ratio: float = 0.1, light_max_ratio: float = 0.4, light_max_angle: float = 40.0,
+                 armor_center_distances: Sequence[float] = (0.8, 3.2, 3.2, 5.5), warmup: int = 0):
         L = capi.load()
         cfg = capi.EngineCfg()
         L.irmv_engine_cfg_default(C.byref(cfg))
@@ -105,6 +110,10 @@ class YoloEngine:
         cfg.score_thr, cfg.iou_thr, cfg.max_det, cfg.pre_nms_cap = score_thr, iou_thr, max_det, pre_nms_cap
         cfg.num_slots, cfg.armor_size = num_slots, armor_size
         cfg.num_streams = num_streams
+        cfg.point_source, cfg.binary_threshold = point_source, binary_threshold
+        cfg.light_min_ratio, cfg.light_max_ratio, cfg.light_max_angle = light_min_ratio, light_max_ratio, light_max_angle
+        (cfg.armor_min_small_center_distance, cfg.armor_max_small_center_distance,
+         cfg.armor_min_large_center_distance, cfg.armor_max_large_center_distance) = armor_center_distances
         cfg.camera_matrix = (C.c_double * 9)(*camera_matrix)
         cfg.dist_coeffs = (C.c_double * 5)(*(list(dist_coeffs) + [0.0] * 5)[:5])
         self._blob_keepalive = None
@@ -182,6 +191,23 @@ class YoloEngine:
         out = np.empty((h, w, 3), np.uint8)
         capi.check(self._L.irmv_engine_rotated_image(self._h, slot, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
+
+    def extract_armors(self, bboxes, slot: Optional[int] = None) -> List[Armor]:
+        """IrmDetector::extract_armors(get_rotated_image(), bboxes) (src/irm_detector.cpp:292-355) on the GPU,
+        on the slot's current frame; bboxes: `bbox` objects or xyxy rows in rotated-frame pixels.  Returns one
+        Armor per input box (check `.valid`)."""
+        slot = self.slot if slot is None else slot
+        rows = [b.xyxy if isinstance(b, bbox) else b for b in bboxes]
+        xy = np.ascontiguousarray(rows, np.float32).reshape(-1, 4)
+        out = (capi.Det * max(len(xy), 1))()
+        capi.check(self._L.irmv_engine_extract_armors(self._h, slot, xy.ctypes.data_as(C.POINTER(C.c_float)), len(xy), out))
+        res = []
+        for i in range(len(xy)):
+            a = self._to_armor(out[i])
+            if isinstance(bboxes[i], bbox):
+                a.armor_class, a.confidence = bboxes[i].class_id, bboxes[i].score
+            res.append(a)
+        return res
 
     def visualize_bboxes(self, image: np.ndarray, bboxes: Sequence[bbox]) -> None:
         """Draw 2-px rectangles in place; like the reference, print and return on
@@ -282,7 +308,8 @@ class YoloEngine:
         k = list(d.kpts)
         a = Armor(left_light=Light(top=(k[2], k[3]), bottom=(k[0], k[1])),
                   right_light=Light(top=(k[4], k[5]), bottom=(k[6], k[7])),
-                  size=ArmorSize.SMALL, armor_class=ArmorClass(d.class_id), confidence=d.score,
+                  size=ArmorSize(d.armor_size) if d.armor_size in (0, 1) else ArmorSize.UNKNOWN,
+                  armor_class=ArmorClass(d.class_id), confidence=d.score, valid=d.armor_valid == 1, n_lights=d.n_lights, no_answer=d.armor_valid < 0,
                   bbox_xyxy=tuple(d.xyxy), pnp_ok=bool(d.pnp_ok),
                   rvec=np.array(d.rvec), tvec=np.array(d.tvec), quat_xyzw=np.array(d.quat))
         a.center = ((k[0] + k[2] + k[4] + k[6]) / 4.0, (k[1] + k[3] + k[5] + k[7]) / 4.0)

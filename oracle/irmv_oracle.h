@@ -24,6 +24,8 @@
  *   orc_solve_pnp_ippe  src/pnp_solver.cpp:18-51 (cv::solvePnP, SOLVEPNP_IPPE;
  *                       OpenCV calib3d ippe.cpp; Collins & Bartoli IJCV 2014)
  *   orc_rvec_to_quat    src/irm_detector.cpp:218-226 (cv::Rodrigues + tf2 getRotation)
+ *   orc_extract_armor   src/irm_detector.cpp:292-355 + include/irmv_detection/armor.hpp:11-77
+ *                       (cvtColor / threshold / findContours / minAreaRect restated)
  */
 #ifndef IRMV_ORACLE_H
 #define IRMV_ORACLE_H
@@ -111,6 +113,22 @@ void orc_project_points(const double K[9], const double D[5], const double rvec[
 void orc_armor_object_points(int armor_size, double obj[12]);
 void orc_rodrigues(const double rvec[3], double R[9]);
 void orc_rvec_to_quat(const double rvec[3], double quat_xyzw[4]);
+
+/* ---- classical armor-point extraction (row f1; orc_light.c) ---------------- */
+typedef struct orc_light_params {
+    int binary_threshold;                       /* 150  (src/irm_detector.cpp:152) */
+    float light_min_ratio, light_max_ratio;     /* 0.1, 0.4 */
+    float light_max_angle;                      /* 40 degrees */
+    double armor_min_small_center_distance, armor_max_small_center_distance;   /* 0.8, 3.2 */
+    double armor_min_large_center_distance, armor_max_large_center_distance;   /* 3.2, 5.5 */
+} orc_light_params;
+void orc_light_params_default(orc_light_params *P);
+/* external contours (RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) of a binary w x h image, OpenCV order */
+int orc_find_external_contours(const uint8_t *bin, int w, int h, short *pts, int pts_cap, int *offsets, int max_contours);
+void orc_min_area_rect(const short *pts, int n, float corners[8]);
+/* IrmDetector::extract_armors for ONE bbox on the (rotated) u8 HWC frame; pts = LB, LT, RT, RB */
+int orc_extract_armor(const uint8_t *img, int cols, int rows, const float xyxy[4], const orc_light_params *P,
+                      int *size, float pts[8], float center[2], int *n_lights_out);
 
 #ifdef __cplusplus
 }

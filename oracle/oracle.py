@@ -18,8 +18,15 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 RESIZE_STRETCH, RESIZE_LETTERBOX = 0, 1
 
 
+class LightParams(C.Structure):
+    _fields_ = [("binary_threshold", C.c_int), ("light_min_ratio", C.c_float), ("light_max_ratio", C.c_float),
+                ("light_max_angle", C.c_float), ("armor_min_small_center_distance", C.c_double),
+                ("armor_max_small_center_distance", C.c_double), ("armor_min_large_center_distance", C.c_double),
+                ("armor_max_large_center_distance", C.c_double)]
+
+
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("orc_net.c", "orc_post.c", "irmv_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_net.c", "orc_post.c", "orc_light.c", "irmv_oracle.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
@@ -69,6 +76,10 @@ def lib():
         L.orc_armor_object_points.argtypes = [C.c_int, f64p]
         L.orc_rodrigues.argtypes = [f64p, f64p]
         L.orc_rvec_to_quat.argtypes = [f64p, f64p]
+        L.orc_light_params_default.argtypes = [C.POINTER(LightParams)]
+        L.orc_find_external_contours.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(C.c_short), C.c_int, i32p, C.c_int]
+        L.orc_min_area_rect.argtypes = [C.POINTER(C.c_short), C.c_int, f32p]
+        L.orc_extract_armor.argtypes = [u8p, C.c_int, C.c_int, f32p, C.POINTER(LightParams), i32p, f32p, f32p, i32p]
         _lib = L
     return _lib
 
@@ -246,3 +257,42 @@ def rvec_to_quat(rvec) -> np.ndarray:
     q = np.zeros(4)
     lib().orc_rvec_to_quat(_p(rvec, C.c_double), _p(q, C.c_double))
     return q
+
+
+# ---- classical light extraction (row f1) ----------------------------------------
+def light_params(**kw) -> "LightParams":
+    P = LightParams()
+    lib().orc_light_params_default(C.byref(P))
+    for k, v in kw.items():
+        setattr(P, k, v)
+    return P
+
+
+def find_external_contours(binary: np.ndarray):
+    """-> list of int16 [n, 2] (x, y) arrays, OpenCV order (last found first)"""
+    b = np.ascontiguousarray(binary, np.uint8)
+    h, w = b.shape
+    cap = 8 * (w + h) * 8 + 4096
+    pts = np.zeros((cap, 2), np.int16)
+    off = np.zeros(4097, np.int32)
+    n = lib().orc_find_external_contours(_p(b, C.c_uint8), w, h, _p(pts, C.c_short), cap, _p(off, C.c_int), 4096)
+    return [pts[off[i]:off[i + 1]].copy() for i in range(n)]
+
+
+def min_area_rect(pts: np.ndarray) -> np.ndarray:
+    p = np.ascontiguousarray(pts, np.int16).reshape(-1, 2)
+    out = np.zeros(8, np.float32)
+    lib().orc_min_area_rect(_p(p, C.c_short), len(p), _p(out, C.c_float))
+    return out.reshape(4, 2)
+
+
+def extract_armor(img: np.ndarray, xyxy, params=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    rows, cols, _ = img.shape
+    P = params or light_params()
+    box = np.ascontiguousarray(xyxy, np.float32).reshape(4)
+    size, nl = C.c_int(0), C.c_int(0)
+    pts, center = np.zeros(8, np.float32), np.zeros(2, np.float32)
+    ok = lib().orc_extract_armor(_p(img, C.c_uint8), cols, rows, _p(box, C.c_float), C.byref(P), C.byref(size),
+                                 _p(pts, C.c_float), _p(center, C.c_float), C.byref(nl))
+    return dict(ok=bool(ok), size=size.value, pts=pts.reshape(4, 2), center=center, n_lights=nl.value)
