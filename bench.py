@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--frames-per-step", type=int, default=128)
     ap.add_argument("--src", default="1280x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96)

@@ -18,6 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 # (source, extra flags).  k_post.hip must not contract a*b+c: see its header.
 SOURCES = [
     ("k_pre.hip", []),
+    ("k_front.hip", []),
     ("k_conv.hip", []),
     ("k_post.hip", ["-ffp-contract=off"]),
     ("k_light.hip", ["-ffp-contract=off"]),

@@ -100,7 +100,7 @@ struct Tensor {
 
 struct SegRef { int t = -1, coff = 0, C = 0, shift = 0; };
 
-enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_DECODE, OP_NMS, OP_LIGHT };
+enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_DECODE, OP_NMS, OP_LIGHT, OP_FRONT };
 
 struct Op {
     OpKind kind;
@@ -120,6 +120,7 @@ struct Op {
     int level = -1;    // Detect level of a head op: it may start as soon as P(level) exists
     int signal = -1;   // >= 0: this op produces P(signal); side lanes wait on its event
     char kname[48] = {0};
+    bool fused_away = false;   // preprocess / model.0 / model.1 when the fused front kernel runs them (kept for read-backs)
 };
 
 struct GraphKey {
@@ -154,6 +155,9 @@ struct irmv_engine {
     float *head_all = nullptr;
     PnpConst *pnp_dev = nullptr;
     long long *dbg_dev = nullptr;
+    bool fused_front = false;          // OP_FRONT replaces preprocess + model.0.conv + model.1.conv in a step
+    int front_tiles_x = 0, front_tiles_y = 0, front_stage_bytes = 0;
+    int front_v[4] = {0, 0, 0, 0};     // valid (non-padding) net-input column / row ranges
     bool classical = false;            // four points from the classical light extraction instead of a keypoint head
     signed char *light_labels = nullptr;   // label pool: light_pool bytes per slot
     size_t light_pool = 0;
@@ -386,6 +390,41 @@ static void axis_taps(std::vector<AxisTap> &out, int dn_total, int sn, int dn, i
     }
 }
 
+// The fused front kernel (k_front.hip) stages each tile's source region in LDS as 4-byte pixels, read in groups of
+// 4 pixels = three aligned dwords: the width must be a multiple of 4 and the largest region must fit kFrontStageMax
+// bytes of LDS.  Same box arithmetic as the kernel.
+static bool front_fits(const std::vector<AxisTap> &tx, const std::vector<AxisTap> &ty, int net, int sw, int *tiles_x, int *tiles_y, int *stage_bytes)
+{
+    const int W1 = net / 4;
+    *tiles_x = (W1 + kFrontTileX - 1) / kFrontTileX;
+    *tiles_y = (W1 + kFrontTileY - 1) / kFrontTileY;
+    *stage_bytes = front_min_stage_bytes();
+    if (sw % 4 != 0) return false;   // 4-pixel groups = 12 source bytes read as three aligned dwords
+    auto span = [&](const std::vector<AxisTap> &t, int g0, int n, int *lo, int *hi) {
+        *lo = 0x7fffffff; *hi = -1;
+        for (int i = g0; i < g0 + n; i++) {
+            if (i < 0 || i >= net || t[i].i0 < 0) continue;
+            *lo = std::min({*lo, t[i].i0, t[i].i1});
+            *hi = std::max({*hi, t[i].i0, t[i].i1});
+        }
+    };
+    int max_pitch = 0, max_rows = 0;
+    for (int i = 0; i < *tiles_x; i++) {
+        int lo, hi;
+        span(tx, 4 * i * kFrontTileX - 3, 4 * kFrontTileX + 3, &lo, &hi);
+        if (hi >= 0) max_pitch = std::max(max_pitch, std::min((hi + 4) & ~3, sw) - (lo & ~3));
+    }
+    for (int i = 0; i < *tiles_y; i++) {
+        int lo, hi;
+        span(ty, 4 * i * kFrontTileY - 3, 4 * kFrontTileY + 3, &lo, &hi);
+        if (hi >= 0) max_rows = std::max(max_rows, hi - lo + 1);
+    }
+    if (max_pitch > 1023 || max_rows > 1023) return false;   // region-relative taps are packed in 10 bits
+    const size_t need = (size_t)max_pitch * max_rows * 4;
+    *stage_bytes = std::max((int)std::min<size_t>((need + 255) & ~(size_t)255, 1u << 30), front_min_stage_bytes());
+    return need <= (size_t)kFrontStageMax;
+}
+
 static int autotune_convs(irmv_engine *e);
 
 static int build_engine(irmv_engine *e)
@@ -427,6 +466,10 @@ static int build_engine(irmv_engine *e)
     TRY(dev_alloc(e, (void **)&e->tap_y, net * sizeof(AxisTap)));
     HIP_TRY(hipMemcpy(e->tap_x, tx.data(), net * sizeof(AxisTap), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->tap_y, ty.data(), net * sizeof(AxisTap), hipMemcpyHostToDevice));
+    e->fused_front = front_fits(tx, ty, net, c.src_width, &e->front_tiles_x, &e->front_tiles_y, &e->front_stage_bytes);
+    e->front_v[0] = px; e->front_v[1] = px + nw; e->front_v[2] = py; e->front_v[3] = py + nh;
+    if (const char *ff = getenv("IRMV_FUSED_FRONT")) if (ff[0] == '0') e->fused_front = false;
+    if (e->fused_front && !front_prepare()) e->fused_front = false;
 
     // ---- graph ----
     const int s2 = net / 2, s4 = net / 4, s8 = net / 8, s16 = net / 16, s32 = net / 32;
@@ -478,6 +521,18 @@ static int build_engine(irmv_engine *e)
         e->ops.push_back(op);
     }
     TRY(add_conv(e, "model.1.conv", SegRef{a0, 0, 16, 0}, SegRef{}, s2, s2, a1, 0));
+    {
+        const Op &m1 = e->ops.back();
+        if (!(m1.cfg.cin16 && m1.ksteps == 5 && m1.pair && m1.cout_pad == 32 && m1.out_coff == 0)) e->fused_front = false;
+        if (e->fused_front) {
+            Op op; op.kind = OP_FRONT; op.layer = "preprocess+model.0+model.1"; snprintf(op.kname, sizeof op.kname, "front_fused");
+            op.flops = e->ops[1].flops + m1.flops;
+            op.bytes = (double)e->frame_bytes + (double)s4 * s4 * 32 * 2;
+            op.w_packed = m1.w_packed; op.bias = m1.bias; op.out_t = m1.out_t;
+            for (Op &o : e->ops) o.fused_away = true;   // preprocess, model.0.conv, model.1.conv
+            e->ops.push_back(op);
+        }
+    }
     TRY(add_c2f(e, "model.2", SegRef{a1, 0, 32, 0}, SegRef{}, s4, s4, 32, 1, true, a2));
     TRY(add_conv(e, "model.3.conv", SegRef{a2, 0, 32, 0}, SegRef{}, s4, s4, a3, 0));
     TRY(add_c2f(e, "model.4", SegRef{a3, 0, 64, 0}, SegRef{}, s8, s8, 64, 2, true, a4));
@@ -696,7 +751,7 @@ extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
     if (cfg->struct_size != sizeof(irmv_engine_cfg)) return fail(IRMV_ERR_ARG, "irmv_engine_cfg size mismatch");
     if (cfg->net_size < 64 || cfg->net_size % 32 != 0 || cfg->net_size > 2048) return fail(IRMV_ERR_ARG, "net_size must be a multiple of 32 in [64, 2048]");
     if (cfg->src_width < 2 || cfg->src_height < 2 || cfg->src_width > 4096) return fail(IRMV_ERR_ARG, "src size out of range (width <= 4096)");
-    if (cfg->num_slots < 1 || cfg->num_slots > 64) return fail(IRMV_ERR_ARG, "num_slots must be 1..64");
+    if (cfg->num_slots < 1 || cfg->num_slots > 256) return fail(IRMV_ERR_ARG, "num_slots must be 1..256");
     if (cfg->max_det < 1 || cfg->max_det > IRMV_MAX_DET_CAP) return fail(IRMV_ERR_ARG, "max_det must be 1..256");
     if (cfg->pre_nms_cap < 1 || cfg->pre_nms_cap > IRMV_CAND_CAP) return fail(IRMV_ERR_ARG, "pre_nms_cap must be 1..8192");
     if (!(cfg->score_thr > 0.f && cfg->score_thr < 1.f)) return fail(IRMV_ERR_ARG, "score_thr must be in (0, 1)");
@@ -867,7 +922,7 @@ static int autotune_convs(irmv_engine *e)
 }
 
 // ---- step execution ------------------------------------------------------------
-struct EvRec { hipEvent_t a, b; };
+struct EvRec { hipEvent_t a = nullptr, b = nullptr; int op = -1; };
 constexpr uint32_t kProfileRepeat = 4;   // launches per event bracket in irmv_engine_profile
 
 static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int count, ConvArgs &a)
@@ -961,6 +1016,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     int lane_level[3] = {-1, -1, -1};
     for (const Op &op : e->ops) {
         if (post_only && op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) continue;
+        if (op.fused_away) continue;
         hipStream_t s = e->stream;
         if (fork && op.lane > 0) {
             const int ln = op.lane - 1;
@@ -979,6 +1035,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
                 }
         }
         EvRec r{};
+        r.op = (int)(&op - e->ops.data());
         if (ev) {
             HIP_TRY(hipEventCreate(&r.a));
             HIP_TRY(hipEventCreate(&r.b));
@@ -995,6 +1052,23 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             a.sw = e->cfg.src_width; a.sh = e->cfg.src_height; a.net = net; a.swap_rb = e->cfg.swap_rb;
             a.src_slot_bytes = e->frame_bytes;
             launch_preprocess(a, count, s);
+            break;
+        }
+        case OP_FRONT: {
+            FrontArgs a;
+            a.src = e->src_dev + (size_t)first * e->frame_bytes;
+            a.src_slot_bytes = e->frame_bytes;
+            a.tx = e->tap_x; a.ty = e->tap_y;
+            a.vx0 = e->front_v[0]; a.vx1 = e->front_v[1]; a.vy0 = e->front_v[2]; a.vy1 = e->front_v[3];
+            a.sw = e->cfg.src_width; a.sh = e->cfg.src_height; a.net = net; a.swap_rb = e->cfg.swap_rb;
+            a.w0 = e->conv0_w; a.b0 = e->conv0_b;
+            a.w1 = op.w_packed; a.b1 = op.bias;
+            const Tensor &ot = e->tensors[op.out_t];
+            a.out = static_cast<half_t *>(ot.slot(first));
+            a.out_ld = ot.C;
+            a.tiles_x = e->front_tiles_x; a.tiles_y = e->front_tiles_y;
+            a.stage_bytes = e->front_stage_bytes;
+            if (!launch_front(a, count, s)) return fail(IRMV_ERR_HIP, "fused front kernel: LDS request refused");
             break;
         }
         case OP_CONV0: {
@@ -1228,9 +1302,35 @@ static int read_tensor_f32(irmv_engine *e, const Tensor &t, int slot, std::vecto
     return IRMV_OK;
 }
 
+// With the fused front a step never writes the "input" and "0" tensors: a read-back of one of them runs the
+// stand-alone preprocess / model.0 kernels on the slot's current device frame first.
+static int materialize_front(irmv_engine *e, int slot)
+{
+    if (!e->fused_front) return IRMV_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    TRY(irmv_engine_wait(e));
+    const int net = e->cfg.net_size;
+    PreArgs p;
+    p.src = e->src_dev + (size_t)slot * e->frame_bytes;
+    p.dst = static_cast<half_t *>(e->tensors[e->tensor_idx.at("input")].slot(slot));
+    p.tx = e->tap_x; p.ty = e->tap_y;
+    p.sw = e->cfg.src_width; p.sh = e->cfg.src_height; p.net = net; p.swap_rb = e->cfg.swap_rb;
+    p.src_slot_bytes = e->frame_bytes;
+    launch_preprocess(p, 1, e->stream);
+    Conv0Args a;
+    a.x = p.dst;
+    a.y = static_cast<half_t *>(e->tensors[e->tensor_idx.at("0")].slot(slot));
+    a.w = e->conv0_w; a.b = e->conv0_b; a.net = net; a.batch = 1;
+    launch_conv0(a, e->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return IRMV_OK;
+}
+
 extern "C" int irmv_engine_read_input(irmv_engine *e, int slot, float *chw)
 {
     TRY(check_range(e, slot, 1));
+    TRY(materialize_front(e, slot));
     std::vector<float> v;
     TRY(read_tensor_f32(e, e->tensors[e->tensor_idx.at("input")], slot, v));
     const size_t n = (size_t)e->cfg.net_size * e->cfg.net_size;
@@ -1284,6 +1384,7 @@ extern "C" int irmv_engine_read_tap(irmv_engine *e, int slot, const char *name, 
     const Tensor &t = e->tensors[it->second];
     shape[0] = t.H; shape[1] = t.W; shape[2] = t.C;
     if (!nhwc) return IRMV_OK;
+    if (t.name == "input" || t.name == "0") TRY(materialize_front(e, slot));
     std::vector<float> v;
     TRY(read_tensor_f32(e, t, slot, v));
     memcpy(nhwc, v.data(), v.size() * 4);
@@ -1329,7 +1430,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
         HIP_TRY(hipEventElapsedTime(&ms, ev[i].a, ev[i].b));
         (void)hipEventDestroy(ev[i].a);
         (void)hipEventDestroy(ev[i].b);
-        const Op &op = e->ops[i];
+        const Op &op = e->ops[ev[i].op];
         if (op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) ms /= (float)kProfileRepeat;
         if (k < cap && stats) {
             irmv_kernel_stat &st = stats[k];

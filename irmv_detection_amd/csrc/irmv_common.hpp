@@ -46,6 +46,28 @@ struct Conv0Args {
 };
 void launch_conv0(const Conv0Args &a, hipStream_t s);
 
+// fused front: preprocess + model.0.conv + model.1.conv (k_front.hip)
+constexpr int kFrontTileY = 8, kFrontTileX = 16;   // model.1 output tile of one workgroup
+constexpr int kFrontStageMax = 128 * 1024;         // most LDS the tile's source region may take (else: the three kernels)
+struct FrontArgs {
+    const uint8_t *src;   // [B][sh][sw][3]
+    size_t src_slot_bytes;
+    const AxisTap *tx, *ty;
+    int vx0, vx1, vy0, vy1;   // net-input columns / rows with a source tap: [v0, v1) (the rest is letterbox padding)
+    int sw, sh, net, swap_rb;
+    const half_t *w0;     // model.0.conv fragments (Conv0Args::w)
+    const float *b0;
+    const half_t *w1;     // model.1.conv, direct-family packing (Cin = 16: 5 k-steps x 2 paired tiles)
+    const float *b1;
+    half_t *out;          // [B][net/4][net/4][out_ld]
+    int out_ld;
+    int tiles_x, tiles_y;
+    int stage_bytes;      // dynamic LDS: >= the largest tile's source region and >= front_min_stage_bytes()
+};
+int front_min_stage_bytes();
+bool front_prepare();
+bool launch_front(const FrontArgs &a, int batch, hipStream_t s);
+
 // ---- implicit-GEMM conv on MFMA ----------------------------------------------
 struct ConvSeg {
     const half_t *p;  // base pointer, already offset to the segment's first channel

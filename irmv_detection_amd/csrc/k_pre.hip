@@ -18,6 +18,8 @@ constexpr int kMaxRowBytes = 4096 * 3;
 __global__ __launch_bounds__(256) void preprocess_kernel(PreArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t rows[2][kMaxRowBytes];
+    __shared__ half_t lut[256];   // (half)(q / 255.0f)
+    lut[threadIdx.x] = (half_t)((float)threadIdx.x / 255.0f);
     const int dy = blockIdx.x, b = blockIdx.y;
     const AxisTap ty = a.ty[dy];
     const int row_bytes = a.sw * 3;
@@ -51,19 +53,19 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreArgs a)
             o = (half4){padv, padv, padv, (half_t)0.0f};
         } else {
             const uint32_t wx = (uint32_t)tx.w1;
-            float v[3];
+            half_t v[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const uint32_t p00 = rows[0][tx.i0 * 3 + c], p01 = rows[0][tx.i1 * 3 + c];
                 const uint32_t p10 = rows[1][tx.i0 * 3 + c], p11 = rows[1][tx.i1 * 3 + c];
-                const uint32_t top = (kCoefOne - wx) * p00 + wx * p01;
-                const uint32_t bot = (kCoefOne - wx) * p10 + wx * p11;
-                const uint32_t acc = (kCoefOne - wy) * top + wy * bot;
-                const uint32_t q = (acc + (1u << (2 * kCoefBits - 1))) >> (2 * kCoefBits);
-                v[c] = (float)q / 255.0f;
+                // 24-bit multiplies (full rate): coefficients <= 2^11, pixels < 2^8, top / bot < 2^19
+                const uint32_t top = __umul24(kCoefOne - wx, p00) + __umul24(wx, p01);
+                const uint32_t bot = __umul24(kCoefOne - wx, p10) + __umul24(wx, p11);
+                const uint32_t acc = __umul24(kCoefOne - wy, top) + __umul24(wy, bot);
+                v[c] = lut[(acc + (1u << (2 * kCoefBits - 1))) >> (2 * kCoefBits)];
             }
-            if (a.swap_rb) { const float t = v[0]; v[0] = v[2]; v[2] = t; }
-            o = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)0.0f};
+            if (a.swap_rb) { const half_t t = v[0]; v[0] = v[2]; v[2] = t; }
+            o = (half4){v[0], v[1], v[2], (half_t)0.0f};
         }
         *reinterpret_cast<half4 *>(dst + (size_t)dx * 4) = o;
     }

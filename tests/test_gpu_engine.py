@@ -339,3 +339,32 @@ def test_tile_choice_is_bitwise_neutral(blob, frame0):
                 e.detect(0)                       # single-frame step on the batched engine: its own tile set
                 heads.append(e.read_head(0).copy())
     assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2])
+
+
+@pytest.mark.parametrize("size,net,mode,rot,swap,fused", [
+    ((1280, 1024), 640, 0, True, False, True),     # reference configuration
+    ((1280, 1024), 640, 0, False, True, True),
+    ((1280, 1024), 640, 1, True, False, True),     # letterbox: pad rows inside tiles
+    ((640, 640), 640, 0, True, False, True),       # BASELINE configs[1]
+    ((1280, 1024), 416, 0, True, False, True),     # 104 x 104 output: partial tiles
+    ((1920, 1200), 640, 1, True, False, True),     # 3x down-scale: 87 KB source region per tile, one workgroup per CU
+    ((641, 479), 640, 0, True, False, False),      # width not a multiple of 4: falls back to the three kernels
+    ((4096, 3000), 640, 0, True, False, False),    # tile's source region larger than the LDS stage: falls back
+])
+def test_fused_front_is_bitwise_identical(blob, monkeypatch, size, net, mode, rot, swap, fused):
+    """preprocess + model.0 + model.1 in one kernel (k_front.hip) == the three separate kernels, bit for bit."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (size[1], size[0], 3), dtype=np.uint8)
+    img[: size[1] // 2] = frames.synthetic_frame(3, size[0], size[1])[: size[1] // 2]
+    got = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("IRMV_FUSED_FRONT", env)
+        with YoloEngine(None, size, weights_blob=blob, net_size=net, resize_mode=mode, rotate180=rot, swap_rb=swap) as e:
+            names = [st["name"] for st in e.profile(0, 1)]
+            assert ("front_fused" in names) == (env == "1" and fused)
+            _load(e, 0, img)
+            e.detect()
+            got.append((e.read_tap("1", 0).copy(), e.read_head(0).copy(), e.read_input(0).copy(), e.read_tap("0", 0).copy()))
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+    assert np.abs(got[0][0]).max() > 0.1

@@ -83,3 +83,10 @@ def test_rm_test_jpg_golden(rm_test_image):
     x, u8 = oracle.preprocess(rm_test_image, 640, 0, True, False, want_u8=True)
     assert zlib.crc32(u8.tobytes()) == meta["u8_crc32"]
     assert zlib.crc32(x.astype(np.float16).tobytes()) == meta["fp16_chw_crc32"]
+
+
+def test_u8_to_unit_fp16_by_reciprocal_is_exact():
+    """The HIP kernels compute (half)(q * (1/255)) instead of the oracle's (half)(q / 255.0f): identical for all 256 inputs."""
+    q = np.arange(256, dtype=np.float32)
+    assert np.array_equal((q / np.float32(255.0)).astype(np.float16),
+                          (q * (np.float32(1.0) / np.float32(255.0))).astype(np.float16))
