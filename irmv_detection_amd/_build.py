@@ -19,6 +19,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 SOURCES = [
     ("k_pre.hip", []),
     ("k_front.hip", []),
+    ("k_c2f.hip", []),
     ("k_conv.hip", []),
     ("k_post.hip", ["-ffp-contract=off"]),
     ("k_light.hip", ["-ffp-contract=off"]),

@@ -100,7 +100,7 @@ struct Tensor {
 
 struct SegRef { int t = -1, coff = 0, C = 0, shift = 0; };
 
-enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_DECODE, OP_NMS, OP_LIGHT, OP_FRONT };
+enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_DECODE, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2 };
 
 struct Op {
     OpKind kind;
@@ -120,6 +120,7 @@ struct Op {
     int level = -1;    // Detect level of a head op: it may start as soon as P(level) exists
     int signal = -1;   // >= 0: this op produces P(signal); side lanes wait on its event
     char kname[48] = {0};
+    int sub[4] = {-1, -1, -1, -1};   // OP_C2F2: indices of the four layer ops whose weights it uses
     bool fused_away = false;   // preprocess / model.0 / model.1 when the fused front kernel runs them (kept for read-backs)
 };
 
@@ -534,6 +535,25 @@ static int build_engine(irmv_engine *e)
         }
     }
     TRY(add_c2f(e, "model.2", SegRef{a1, 0, 32, 0}, SegRef{}, s4, s4, 32, 1, true, a2));
+    {
+        // model.2 as one kernel (k_c2f.hip) when its four layers have the shapes that kernel is written for
+        const int n = (int)e->ops.size();
+        const Op &c1 = e->ops[n - 4], &m1 = e->ops[n - 3], &m2 = e->ops[n - 2], &c2 = e->ops[n - 1];
+        bool ok = c1.cin == 32 && c1.cout == 32 && c1.cfg.ks == 1 && c1.pair && c1.ksteps == 1 &&
+                  m1.cin == 16 && m1.cout == 16 && m1.cfg.cin16 && m1.ksteps == 5 && !m1.pair &&
+                  m2.cin == 16 && m2.cout == 16 && m2.cfg.cin16 && m2.ksteps == 5 && !m2.pair && m2.res_t >= 0 &&
+                  c2.cin == 48 && c2.cout == 32 && c2.cfg.ks == 1 && c2.pair && c2.ksteps == 2 &&
+                  c1.cfg.act == 1 && m1.cfg.act == 1 && m2.cfg.act == 1 && c2.cfg.act == 1;
+        if (const char *ff = getenv("IRMV_FUSED_C2F")) if (ff[0] == '0') ok = false;
+        if (ok) {
+            Op op; op.kind = OP_C2F2; op.layer = "model.2 (cv1+m.0+cv2)"; snprintf(op.kname, sizeof op.kname, "c2f2_fused");
+            op.flops = c1.flops + m1.flops + m2.flops + c2.flops;
+            op.bytes = 2.0 * (double)s4 * s4 * 32 * 2;
+            for (int i = 0; i < 4; i++) { op.sub[i] = n - 4 + i; e->ops[n - 4 + i].fused_away = true; }
+            op.s0 = c1.s0; op.out_t = c2.out_t;
+            e->ops.push_back(op);
+        }
+    }
     TRY(add_conv(e, "model.3.conv", SegRef{a2, 0, 32, 0}, SegRef{}, s4, s4, a3, 0));
     TRY(add_c2f(e, "model.4", SegRef{a3, 0, 64, 0}, SegRef{}, s8, s8, 64, 2, true, a4));
     TRY(add_conv(e, "model.5.conv", SegRef{a4, 0, 64, 0}, SegRef{}, s8, s8, a5, 0));
@@ -1007,6 +1027,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
 {
     const int net = e->cfg.net_size;
     const bool capturing = (flags & 0x40000000u) != 0;
+    const bool materialize = (flags & 0x20000000u) != 0;
     HIP_TRY(hipMemsetAsync(e->counts + (size_t)first * kCountStride, 0, (size_t)count * kCountStride * 4, e->stream));
     const PostArgs pa = post_args(e, first);
     // Under capture the three Detect branches ride side streams: branch chains of level i depend only on
@@ -1016,7 +1037,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     int lane_level[3] = {-1, -1, -1};
     for (const Op &op : e->ops) {
         if (post_only && op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) continue;
-        if (op.fused_away) continue;
+        if (op.fused_away != materialize) continue;   // a step skips the layers a fused kernel covers; a read-back runs only those
         hipStream_t s = e->stream;
         if (fork && op.lane > 0) {
             const int ln = op.lane - 1;
@@ -1069,6 +1090,18 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             a.tiles_x = e->front_tiles_x; a.tiles_y = e->front_tiles_y;
             a.stage_bytes = e->front_stage_bytes;
             if (!launch_front(a, count, s)) return fail(IRMV_ERR_HIP, "fused front kernel: LDS request refused");
+            break;
+        }
+        case OP_C2F2: {
+            C2fArgs a;
+            const Tensor &xt = e->tensors[op.s0.t], &ot = e->tensors[op.out_t];
+            a.x = static_cast<const half_t *>(xt.slot(first)); a.x_ld = xt.C;
+            a.out = static_cast<half_t *>(ot.slot(first)); a.out_ld = ot.C;
+            a.S = xt.H; a.tiles = (xt.H + kC2fTile - 1) / kC2fTile;
+            const Op &c1 = e->ops[op.sub[0]], &m1 = e->ops[op.sub[1]], &m2 = e->ops[op.sub[2]], &c2 = e->ops[op.sub[3]];
+            a.w_cv1 = c1.w_packed; a.w_m1 = m1.w_packed; a.w_m2 = m2.w_packed; a.w_cv2 = c2.w_packed;
+            a.b_cv1 = c1.bias; a.b_m1 = m1.bias; a.b_m2 = m2.bias; a.b_cv2 = c2.bias;
+            launch_c2f2(a, count, s);
             break;
         }
         case OP_CONV0: {
@@ -1302,27 +1335,16 @@ static int read_tensor_f32(irmv_engine *e, const Tensor &t, int slot, std::vecto
     return IRMV_OK;
 }
 
-// With the fused front a step never writes the "input" and "0" tensors: a read-back of one of them runs the
-// stand-alone preprocess / model.0 kernels on the slot's current device frame first.
-static int materialize_front(irmv_engine *e, int slot)
+// A step never writes the tensors inside a fused kernel ("input", "0", "model.2.cat", "model.2.tmp"): a read-back of one of
+// them first runs the stand-alone layers the fused kernels cover, on the slot's current device frame.
+static int materialize_fused(irmv_engine *e, int slot)
 {
-    if (!e->fused_front) return IRMV_OK;
+    bool any = false;
+    for (const Op &op : e->ops) any = any || op.fused_away;
+    if (!any) return IRMV_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
     TRY(irmv_engine_wait(e));
-    const int net = e->cfg.net_size;
-    PreArgs p;
-    p.src = e->src_dev + (size_t)slot * e->frame_bytes;
-    p.dst = static_cast<half_t *>(e->tensors[e->tensor_idx.at("input")].slot(slot));
-    p.tx = e->tap_x; p.ty = e->tap_y;
-    p.sw = e->cfg.src_width; p.sh = e->cfg.src_height; p.net = net; p.swap_rb = e->cfg.swap_rb;
-    p.src_slot_bytes = e->frame_bytes;
-    launch_preprocess(p, 1, e->stream);
-    Conv0Args a;
-    a.x = p.dst;
-    a.y = static_cast<half_t *>(e->tensors[e->tensor_idx.at("0")].slot(slot));
-    a.w = e->conv0_w; a.b = e->conv0_b; a.net = net; a.batch = 1;
-    launch_conv0(a, e->stream);
-    HIP_TRY(hipGetLastError());
+    TRY(enqueue_step(e, slot, 1, 0x20000000u, false, nullptr));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return IRMV_OK;
 }
@@ -1330,7 +1352,7 @@ static int materialize_front(irmv_engine *e, int slot)
 extern "C" int irmv_engine_read_input(irmv_engine *e, int slot, float *chw)
 {
     TRY(check_range(e, slot, 1));
-    TRY(materialize_front(e, slot));
+    TRY(materialize_fused(e, slot));
     std::vector<float> v;
     TRY(read_tensor_f32(e, e->tensors[e->tensor_idx.at("input")], slot, v));
     const size_t n = (size_t)e->cfg.net_size * e->cfg.net_size;
@@ -1384,7 +1406,7 @@ extern "C" int irmv_engine_read_tap(irmv_engine *e, int slot, const char *name, 
     const Tensor &t = e->tensors[it->second];
     shape[0] = t.H; shape[1] = t.W; shape[2] = t.C;
     if (!nhwc) return IRMV_OK;
-    if (t.name == "input" || t.name == "0") TRY(materialize_front(e, slot));
+    if (t.name == "input" || t.name == "0" || t.name == "model.2.cat" || t.name == "model.2.tmp") TRY(materialize_fused(e, slot));
     std::vector<float> v;
     TRY(read_tensor_f32(e, t, slot, v));
     memcpy(nhwc, v.data(), v.size() * 4);

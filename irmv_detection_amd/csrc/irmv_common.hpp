@@ -68,6 +68,19 @@ int front_min_stage_bytes();
 bool front_prepare();
 bool launch_front(const FrontArgs &a, int batch, hipStream_t s);
 
+// fused model.2 (C2f: cv1, one shortcut Bottleneck of two 3x3 16 -> 16 convs, cv2) (k_c2f.hip)
+constexpr int kC2fTile = 16;
+struct C2fArgs {
+    const half_t *x;      // block input [B][S][S][x_ld], 32 channels used
+    int x_ld;
+    half_t *out;          // block output [B][S][S][out_ld], 32 channels
+    int out_ld;
+    int S, tiles;         // spatial size, tiles per side
+    const half_t *w_cv1, *w_m1, *w_m2, *w_cv2;   // direct-family packings of the four layers
+    const float *b_cv1, *b_m1, *b_m2, *b_cv2;
+};
+void launch_c2f2(const C2fArgs &a, int batch, hipStream_t s);
+
 // ---- implicit-GEMM conv on MFMA ----------------------------------------------
 struct ConvSeg {
     const half_t *p;  // base pointer, already offset to the segment's first channel

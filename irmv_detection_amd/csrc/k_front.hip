@@ -17,7 +17,7 @@
 // so a frame costs 3.93 MB read + 1.64 MB written.  Every value is rounded to fp16
 // exactly where the unfused kernels store their tensors and every MFMA sees the same
 // operands in the same order, so the result is bit-identical to the three-kernel path
-// (tests/test_gpu_engine.py::test_fused_front_is_bitwise_identical).
+// (tests/test_gpu_engine.py::test_fused_kernels_are_bitwise_identical).
 #include "irmv_common.hpp"
 
 namespace irmv {

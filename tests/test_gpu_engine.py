@@ -351,20 +351,24 @@ def test_tile_choice_is_bitwise_neutral(blob, frame0):
     ((641, 479), 640, 0, True, False, False),      # width not a multiple of 4: falls back to the three kernels
     ((4096, 3000), 640, 0, True, False, False),    # tile's source region larger than the LDS stage: falls back
 ])
-def test_fused_front_is_bitwise_identical(blob, monkeypatch, size, net, mode, rot, swap, fused):
-    """preprocess + model.0 + model.1 in one kernel (k_front.hip) == the three separate kernels, bit for bit."""
+def test_fused_kernels_are_bitwise_identical(blob, monkeypatch, size, net, mode, rot, swap, fused):
+    """preprocess + model.0 + model.1 in one kernel (k_front.hip) and model.2 in one kernel (k_c2f.hip) == the
+    seven separate kernels, bit for bit."""
     rng = np.random.default_rng(11)
     img = rng.integers(0, 256, (size[1], size[0], 3), dtype=np.uint8)
     img[: size[1] // 2] = frames.synthetic_frame(3, size[0], size[1])[: size[1] // 2]
     got = []
     for env in ("1", "0"):
         monkeypatch.setenv("IRMV_FUSED_FRONT", env)
+        monkeypatch.setenv("IRMV_FUSED_C2F", env)
         with YoloEngine(None, size, weights_blob=blob, net_size=net, resize_mode=mode, rotate180=rot, swap_rb=swap) as e:
             names = [st["name"] for st in e.profile(0, 1)]
             assert ("front_fused" in names) == (env == "1" and fused)
+            assert ("c2f2_fused" in names) == (env == "1")
             _load(e, 0, img)
             e.detect()
-            got.append((e.read_tap("1", 0).copy(), e.read_head(0).copy(), e.read_input(0).copy(), e.read_tap("0", 0).copy()))
+            got.append((e.read_tap("1", 0).copy(), e.read_head(0).copy(), e.read_input(0).copy(), e.read_tap("0", 0).copy(),
+                        e.read_tap("2", 0).copy(), e.read_tap("model.2.cat", 0).copy()))
     for a, b in zip(got[0], got[1]):
         assert np.array_equal(a, b)
     assert np.abs(got[0][0]).max() > 0.1
