@@ -329,6 +329,7 @@ static int add_conv(irmv_engine *e, const std::string &layer, SegRef s0, SegRef 
     op.cfg.ks = l->k; op.cfg.stride = l->stride; op.cfg.act = l->act; op.cfg.out_f32 = ot.f32;
     op.cfg.cin16 = (l->cin == 16 && l->k == 3);
     op.cfg.lds = false;
+    op.cfg.ipw = 1;
     const int nt_all = cout_pad / 16;
     op.cfg.nt = nt_all >= 4 ? 4 : nt_all;
     // enough workgroups to cover 256 CUs a few times, else halve the pixel tile
@@ -827,10 +828,10 @@ static void tune_cache_load()
     if (!path) return;
     std::ifstream f(path);
     std::string key;
-    int mt, nt, lds;
-    while (f >> key >> mt >> nt >> lds) {
+    int mt, nt, lds, ipw;
+    while (f >> key >> mt >> nt >> lds >> ipw) {
         ConvCfg c{};
-        c.mt = mt; c.nt = nt; c.lds = lds != 0;
+        c.mt = mt; c.nt = nt; c.lds = lds != 0; c.ipw = ipw;
         g_tune_cache[key] = c;
     }
 }
@@ -840,19 +841,20 @@ static void tune_cache_save()
     const char *path = getenv("IRMV_TUNE_CACHE");
     if (!path) return;
     std::ofstream f(path);
-    for (auto &kv : g_tune_cache) f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << (kv.second.lds ? 1 : 0) << '\n';
+    for (auto &kv : g_tune_cache) f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << (kv.second.lds ? 1 : 0) << ' ' << kv.second.ipw << '\n';
 }
 
 static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int count, hipStream_t s)
 {
     const int li = c.nt == 4 ? 2 : (c.nt == 2 ? 1 : 0);
-    if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, a, op.w_lds[li], count, s);
+    if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s);
     return launch_conv(c, a, s);
 }
 
 static void cfg_name(const ConvCfg &c, char *buf, int n)
 {
-    if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d", c.stride, c.mt, c.nt);
+    if (c.lds && c.ipw > 1) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d_i%d", c.stride, c.mt, c.nt, c.ipw);
+    else if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d", c.stride, c.mt, c.nt);
     else conv_cfg_name(c, buf, n);
 }
 
@@ -899,15 +901,16 @@ static int autotune_convs(irmv_engine *e)
             auto hit = g_tune_cache.find(key);
             if (hit != g_tune_cache.end() && !verbose) {
                 best_cfg = op.cfg;
-                best_cfg.mt = hit->second.mt; best_cfg.nt = hit->second.nt; best_cfg.lds = hit->second.lds;
+                best_cfg.mt = hit->second.mt; best_cfg.nt = hit->second.nt; best_cfg.lds = hit->second.lds; best_cfg.ipw = hit->second.ipw;
                 best = 0.f;
             } else
             for (int fam = lds_ok ? 1 : 0; fam <= (lds_ok ? 1 : 0); fam++)
                 for (int mt = 1; mt <= 4; mt *= 2)
-                    for (int nt = 1; nt <= 4; nt *= 2) {
+                    for (int nt = 1; nt <= 4; nt *= 2)
+                    for (int ipw = 1; ipw <= (fam == 1 ? std::min(4, counts[pass]) : 1); ipw *= 2) {
                         if (op.cout_pad % (16 * nt) != 0) continue;
                         ConvCfg c = op.cfg;
-                        c.mt = mt; c.nt = nt; c.lds = fam == 1;
+                        c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw;
                         bool ok = true;
                         for (int i = 0; i < 2 && ok; i++) ok = run_conv(op, c, a, counts[pass], e->stream);
                         if (!ok) continue;

@@ -106,13 +106,13 @@ struct ConvArgs {
     int pair;           // weight rows packed with the paired-tile channel permutation
 };
 
-struct ConvCfg { int ks, stride, mt, nt; bool cin16; int act; bool out_f32; bool lds; };
+struct ConvCfg { int ks, stride, mt, nt; bool cin16; int act; bool out_f32; bool lds; int ipw; };   // ipw: images per workgroup (LDS family)
 // returns false if no instantiation exists for cfg
 bool launch_conv(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 const char *conv_cfg_name(const ConvCfg &cfg, char *buf, int n);
 // LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt
 size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max);
-bool launch_conv_lds(int stride, int mt, int nt, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s);
+bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s);
 
 // SPPF pooling chain: slice 0 (C ch) of [B][H][W][4C] -> slices 1..3 (5x5, 9x9, 13x13 max)
 void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s);

@@ -266,7 +266,7 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 constexpr int kPixStride = 96;  // bytes per staged pixel (32 ch fp16 + pad)
 
 template <int STRIDE, int MT, int NT, bool TILE2D>
-__global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes)
+__global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
@@ -278,7 +278,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
     //  row run : 64*MT consecutive pixels in row-major order (tiles_x = runs per image): no masked
     //            lanes on 20x20 / 40x40 maps whose sides are not multiples of the block, at the price
     //            of staging full-width rows.
-    const int img = blockIdx.x / (tiles_x * tiles_y), tile = blockIdx.x - img * (tiles_x * tiles_y);
+    // A workgroup keeps its tile position for `ipw` consecutive images: the staging plan below is computed once,
+    // and the load -> LDS -> MFMA pipeline runs through all (image, chunk) steps without draining.
+    const int grp = blockIdx.x / (tiles_x * tiles_y), tile = blockIdx.x - grp * (tiles_x * tiles_y);
+    const int img = grp * ipw, nimg = min(ipw, batch - img);
     const int nblk = blockIdx.y;
     const int HWo = a.Hout * a.Wout;
     int PW, PR, iy_base, ix_base;
@@ -348,17 +351,21 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
     const half8 *wsrc = reinterpret_cast<const half8 *>(wl) + (size_t)nblk * chunks * (9 * NT * 64);
 
     half8 rp[PMAX], rw[WPT];
-    auto issue_loads = [&](int chunk) {
+    const size_t img_stride = (size_t)a.Hin * a.Win * a.s0.ld;
+    int l_im = 0, l_chunk = 0;   // loader position: one (image, chunk) step ahead of the MFMAs
+    auto issue_loads = [&]() {
+        const size_t off = (size_t)l_im * img_stride + (size_t)l_chunk * 32;
 #pragma unroll
         for (int i = 0; i < PMAX; i++) {
             rp[i] = zero8;
-            if (val_p[i]) rp[i] = *reinterpret_cast<const half8 *>(src_p[i] + chunk * 32);
+            if (val_p[i]) rp[i] = *reinterpret_cast<const half8 *>(src_p[i] + off);
         }
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             const int e = tid + i * 256;
-            if (e < 9 * NT * 64) rw[i] = wsrc[(size_t)chunk * (9 * NT * 64) + e];
+            if (e < 9 * NT * 64) rw[i] = wsrc[(size_t)l_chunk * (9 * NT * 64) + e];
         }
+        if (++l_chunk == chunks) { l_chunk = 0; l_im++; }
     };
     auto write_lds = [&]() {
 #pragma unroll
@@ -377,11 +384,65 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue_loads(0);
-    for (int chunk = 0; chunk < chunks; chunk++) {
+    // epilogue of one image (bias, SiLU, shortcut, fp16, NHWC store); clears the accumulators for the next one
+    const int nt0 = nblk * NT;
+    auto store_tile = [&](int im) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            if (mv[mt]) {
+                const size_t m = (size_t)im * HWo + mloc[mt];
+                if constexpr (NT % 2 == 0) {   // pair-packed (host guarantees): 8 contiguous channels per lane
+#pragma unroll
+                    for (int u = 0; u < NT / 2; u++) {
+                        const int c0 = (nt0 / 2 + u) * 32 + g * 8;
+                        float vals[8];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            vals[i] = acc[mt][2 * u][i] + a.bias[c0 + i];
+                            vals[4 + i] = acc[mt][2 * u + 1][i] + a.bias[c0 + 4 + i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
+                        if (a.res) {
+                            const half8 rv = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + c0);
+#pragma unroll
+                            for (int i = 0; i < 8; i++) vals[i] += (float)rv[i];
+                        }
+                        half8 o;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
+                        *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = o;
+                    }
+                } else {
+                    const int t = nt0;
+                    const int c0 = a.pair ? ((t >> 1) * 32 + g * 8 + (t & 1) * 4) : (t * 16 + g * 4);
+                    float vals[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        vals[i] = acc[mt][0][i] + a.bias[c0 + i];
+                        vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
+                    }
+                    if (a.res) {
+                        const half4 rv = *reinterpret_cast<const half4 *>(a.res + m * a.res_ld + c0);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) vals[i] += (float)rv[i];
+                    }
+                    *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) =
+                        (half4){(half_t)vals[0], (half_t)vals[1], (half_t)vals[2], (half_t)vals[3]};
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    const int steps = nimg * chunks;
+    int c_im = 0, c_chunk = 0;
+    issue_loads();
+    for (int s = 0; s < steps; s++) {
         write_lds();
         __syncthreads();
-        if (chunk + 1 < chunks) issue_loads(chunk + 1);   // in flight under the MFMAs below
+        if (s + 1 < steps) issue_loads();   // in flight under the MFMAs (and the epilogue) below
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int kh = tap / 3, kw = tap - kh * 3;
@@ -398,52 +459,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[nt], B[mt], acc[mt][nt], 0, 0, 0);
         }
         __syncthreads();
-    }
-
-    // epilogue (bias, SiLU, shortcut, fp16, NHWC store)
-    const int nt0 = nblk * NT;
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        if (!mv[mt]) continue;
-        const size_t m = (size_t)img * HWo + mloc[mt];
-        if constexpr (NT % 2 == 0) {   // pair-packed (host guarantees): 8 contiguous channels per lane
-#pragma unroll
-            for (int u = 0; u < NT / 2; u++) {
-                const int c0 = (nt0 / 2 + u) * 32 + g * 8;
-                float vals[8];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    vals[i] = acc[mt][2 * u][i] + a.bias[c0 + i];
-                    vals[4 + i] = acc[mt][2 * u + 1][i] + a.bias[c0 + 4 + i];
-                }
-#pragma unroll
-                for (int i = 0; i < 8; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
-                if (a.res) {
-                    const half8 rv = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + c0);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) vals[i] += (float)rv[i];
-                }
-                half8 o;
-#pragma unroll
-                for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
-                *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = o;
-            }
-        } else {
-            const int t = nt0;
-            const int c0 = a.pair ? ((t >> 1) * 32 + g * 8 + (t & 1) * 4) : (t * 16 + g * 4);
-            float vals[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                vals[i] = acc[mt][0][i] + a.bias[c0 + i];
-                vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
-            }
-            if (a.res) {
-                const half4 rv = *reinterpret_cast<const half4 *>(a.res + m * a.res_ld + c0);
-#pragma unroll
-                for (int i = 0; i < 4; i++) vals[i] += (float)rv[i];
-            }
-            *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) =
-                (half4){(half_t)vals[0], (half_t)vals[1], (half_t)vals[2], (half_t)vals[3]};
+        if (++c_chunk == chunks) {
+            store_tile(img + c_im);
+            c_chunk = 0;
+            c_im++;
         }
     }
 }
@@ -493,25 +512,27 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
 }
 
 template <int STRIDE, int MT, int NT, bool TILE2D>
-static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, const LdsGeom &g, hipStream_t s)
+static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int ipw, const LdsGeom &g, hipStream_t s)
 {
     static bool attr_set = false;   // one flag per instantiation
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D>), dim3(g.tiles_x * g.tiles_y * batch, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
-                       wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes);
+    const int groups = (batch + ipw - 1) / ipw;
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
+                       wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch);
 }
 
-bool launch_conv_lds(int stride, int mt, int nt, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s)
+bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s)
 {
     const LdsGeom g = lds_geom(a, stride, mt, nt);
     if (!g.bytes) return false;
+    if (ipw < 1) ipw = 1;
 #define IRMV_LDS(ST_, MT_, NT_)                                                                \
     if (stride == ST_ && mt == MT_ && nt == NT_) {                                             \
-        if (g.tile2d) launch_lds_inst<ST_, MT_, NT_, true>(a, wl, batch, g, s);                \
-        else launch_lds_inst<ST_, MT_, NT_, false>(a, wl, batch, g, s);                        \
+        if (g.tile2d) launch_lds_inst<ST_, MT_, NT_, true>(a, wl, batch, ipw, g, s);                \
+        else launch_lds_inst<ST_, MT_, NT_, false>(a, wl, batch, ipw, g, s);                        \
         return true;                                                                           \
     }
     IRMV_LDS(1, 1, 1) IRMV_LDS(1, 2, 1) IRMV_LDS(1, 4, 1)
