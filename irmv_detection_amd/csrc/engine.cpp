@@ -23,6 +23,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <vector>
@@ -121,6 +122,7 @@ struct Op {
     int signal = -1;   // >= 0: this op produces P(signal); side lanes wait on its event
     char kname[48] = {0};
     int sub[4] = {-1, -1, -1, -1};   // OP_C2F2: indices of the four layer ops whose weights it uses
+    int fuse_next = -1;        // LDS 3x3 conv: index of the 1x1 op computed in its epilogue (Detect-head finals), -1 = none
     bool fused_away = false;   // preprocess / model.0 / model.1 when the fused front kernel runs them (kept for read-backs)
 };
 
@@ -156,6 +158,7 @@ struct irmv_engine {
     float *head_all = nullptr;
     PnpConst *pnp_dev = nullptr;
     long long *dbg_dev = nullptr;
+    std::set<std::string> lazy_tensors;   // tensors a step does not write because a fused kernel keeps them on chip
     bool fused_front = false;          // OP_FRONT replaces preprocess + model.0.conv + model.1.conv in a step
     int front_tiles_x = 0, front_tiles_y = 0, front_stage_bytes = 0;
     int front_v[4] = {0, 0, 0, 0};     // valid (non-padding) net-input column / row ranges
@@ -428,6 +431,7 @@ static bool front_fits(const std::vector<AxisTap> &tx, const std::vector<AxisTap
 }
 
 static int autotune_convs(irmv_engine *e);
+static void finalize_head_fusion(irmv_engine *e);
 
 static int build_engine(irmv_engine *e)
 {
@@ -532,6 +536,7 @@ static int build_engine(irmv_engine *e)
             op.bytes = (double)e->frame_bytes + (double)s4 * s4 * 32 * 2;
             op.w_packed = m1.w_packed; op.bias = m1.bias; op.out_t = m1.out_t;
             for (Op &o : e->ops) o.fused_away = true;   // preprocess, model.0.conv, model.1.conv
+            e->lazy_tensors.insert("input"); e->lazy_tensors.insert("0");
             e->ops.push_back(op);
         }
     }
@@ -552,6 +557,7 @@ static int build_engine(irmv_engine *e)
             op.bytes = 2.0 * (double)s4 * s4 * 32 * 2;
             for (int i = 0; i < 4; i++) { op.sub[i] = n - 4 + i; e->ops[n - 4 + i].fused_away = true; }
             op.s0 = c1.s0; op.out_t = c2.out_t;
+            e->lazy_tensors.insert("model.2.cat"); e->lazy_tensors.insert("model.2.tmp");
             e->ops.push_back(op);
         }
     }
@@ -609,6 +615,14 @@ static int build_engine(irmv_engine *e)
             TRY(add_conv(e, pre + ".1", SegRef{t1, 0, mid[b], 0}, SegRef{}, PS[i], PS[i], t2, 0));
             TRY(add_conv(e, pre + ".2", SegRef{t2, 0, mid[b], 0}, SegRef{}, PS[i], PS[i], e->head_t[i], off[b]));
             for (size_t k = e->ops.size() - 3; k < e->ops.size(); k++) { e->ops[k].lane = 1 + b; e->ops[k].level = i; }
+            {   // the branch's final 1x1 can ride in the epilogue of its second 3x3 (k_conv.hip, N2 > 0)
+                const int i1 = (int)e->ops.size() - 2, i2 = i1 + 1;
+                const Op &o1 = e->ops[i1], &o2 = e->ops[i2];
+                const char *fh = getenv("IRMV_FUSED_HEAD");
+                if (!(fh && fh[0] == '0') && !e->fork_head && o1.cout == 64 && o1.cin % 32 == 0 && o1.pair && o1.res_t < 0 && o1.cfg.stride == 1 &&
+                    o2.cin == 64 && o2.ksteps == 2 && o2.cfg.ks == 1 && o2.cfg.out_f32 && o2.cfg.act == 0 && (o2.cout_pad == 16 || o2.cout_pad == 64))
+                    e->ops[i1].fuse_next = i2;
+            }
         }
 
     // ---- post-processing buffers ----
@@ -791,6 +805,7 @@ extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
     if (rc) return rc;
     rc = autotune_convs(e.get());
     if (rc) return rc;
+    finalize_head_fusion(e.get());
     *out = e.release();
     return IRMV_OK;
 }
@@ -863,7 +878,7 @@ static void cfg_name(const ConvCfg &c, char *buf, int n)
 // family offers and keeps the fastest, once for full batched steps and once for
 // single-frame steps.  All tiles walk K in the same order, so the choice never
 // changes a single output bit (tests/test_gpu_engine.py::test_tile_choice_is_bitwise_neutral).
-static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int count, ConvArgs &a);
+static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int count, ConvArgs &a, bool fused = false);
 
 static int autotune_convs(irmv_engine *e)
 {
@@ -881,7 +896,17 @@ static int autotune_convs(irmv_engine *e)
         if (op.kind != OP_CONV) continue;
         for (int pass = 0; pass < (counts[0] > 1 ? 2 : 1); pass++) {
             ConvArgs a;
-            fill_conv_args(e, op, 0, counts[pass], a);
+            bool want_fuse = op.fuse_next >= 0;
+            fill_conv_args(e, op, 0, counts[pass], a, want_fuse);
+            if (want_fuse) {   // the fused epilogue needs an LDS-family tile that owns all 64 channels (nt = 4)
+                bool f_ok = false;
+                for (int mt = 1; mt <= 4 && !f_ok; mt *= 2) f_ok = !only_direct && op.w_lds[2] && conv_lds_bytes(a, op.cfg.stride, mt, 4, nullptr) > 0;
+                if (!f_ok) {
+                    op.fuse_next = -1;
+                    want_fuse = false;
+                    fill_conv_args(e, op, 0, counts[pass], a, false);
+                }
+            }
             float best = 1e30f;
             ConvCfg best_cfg = pass == 0 ? op.cfg : op.cfg_one;
             // Kernel family by a rule that does not depend on the batch (the two families walk K in
@@ -897,7 +922,7 @@ static int autotune_convs(irmv_engine *e)
             char key[160];
             snprintf(key, sizeof key, "%d|%d.%d.%d.%d.%d.%d|%dx%d>%dx%d|c%d.%d.%d.%d>%d|ld%d.%d.%d|n%d|%d", e->cfg.device, op.cfg.ks, op.cfg.stride,
                      (int)op.cfg.cin16, op.cfg.act, (int)op.cfg.out_f32, (int)lds_ok, a.Hin, a.Win, a.Hout, a.Wout, a.s0.C, a.s1.C, a.s0.shift,
-                     a.s1.shift, a.cout_pad, a.s0.ld, a.s1.ld, a.out_ld, counts[pass], a.res ? 1 : 0);
+                     a.s1.shift, a.cout_pad, a.s0.ld, a.s1.ld, a.out_ld, counts[pass], (a.res ? 1 : 0) + 2 * a.n2);
             auto hit = g_tune_cache.find(key);
             if (hit != g_tune_cache.end() && !verbose) {
                 best_cfg = op.cfg;
@@ -909,6 +934,7 @@ static int autotune_convs(irmv_engine *e)
                     for (int nt = 1; nt <= 4; nt *= 2)
                     for (int ipw = 1; ipw <= (fam == 1 ? std::min(4, counts[pass]) : 1); ipw *= 2) {
                         if (op.cout_pad % (16 * nt) != 0) continue;
+                        if (want_fuse && nt != 4) continue;
                         ConvCfg c = op.cfg;
                         c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw;
                         bool ok = true;
@@ -944,11 +970,27 @@ static int autotune_convs(irmv_engine *e)
     return IRMV_OK;
 }
 
+// A 3x3 conv carries its branch's final 1x1 only if BOTH of its tile choices can (LDS family, nt = 4); then the 1x1
+// op drops out of the step and the tensor between the two is no longer written.
+static void finalize_head_fusion(irmv_engine *e)
+{
+    for (Op &op : e->ops) {
+        if (op.fuse_next < 0) continue;
+        const bool ok = op.cfg.lds && op.cfg.nt == 4 && op.cfg_one.lds && op.cfg_one.nt == 4;
+        if (!ok) { op.fuse_next = -1; continue; }
+        e->ops[op.fuse_next].fused_away = true;
+        e->lazy_tensors.insert(e->tensors[op.out_t].name);
+        const size_t l = strlen(op.kname), l1 = strlen(op.kname_one);
+        snprintf(op.kname + l, sizeof op.kname - l, "+1x1");
+        snprintf(op.kname_one + l1, sizeof op.kname_one - l1, "+1x1");
+    }
+}
+
 // ---- step execution ------------------------------------------------------------
 struct EvRec { hipEvent_t a = nullptr, b = nullptr; int op = -1; };
 constexpr uint32_t kProfileRepeat = 4;   // launches per event bracket in irmv_engine_profile
 
-static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int count, ConvArgs &a)
+static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int count, ConvArgs &a, bool fused)
 {
     auto seg = [&](const SegRef &s) {
         ConvSeg cs{nullptr, 0, 0, 0};
@@ -980,6 +1022,16 @@ static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int co
     a.cout_pad = op.cout_pad;
     a.ksteps = op.ksteps;
     a.pair = op.pair ? 1 : 0;
+    a.w2 = nullptr; a.bias2 = nullptr; a.out2 = nullptr; a.out2_ld = 0; a.n2 = 0;
+    if (fused && op.fuse_next >= 0) {
+        const Op &o2 = e->ops[op.fuse_next];
+        const Tensor &t2 = e->tensors[o2.out_t];
+        a.w2 = o2.w_packed;
+        a.bias2 = o2.bias;
+        a.out2 = static_cast<float *>(t2.slot(first)) + o2.out_coff;
+        a.out2_ld = t2.C;
+        a.n2 = o2.cout_pad / 16;
+    }
 }
 
 static LightArgs light_args(const irmv_engine *e, int first)
@@ -1040,7 +1092,9 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     int lane_level[3] = {-1, -1, -1};
     for (const Op &op : e->ops) {
         if (post_only && op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) continue;
-        if (op.fused_away != materialize) continue;   // a step skips the layers a fused kernel covers; a read-back runs only those
+        // a step skips the layers a fused kernel covers; a read-back runs only those (and the unfused form of a conv that
+        // normally carries a 1x1 in its epilogue)
+        if (materialize ? !(op.fused_away || op.fuse_next >= 0) : op.fused_away) continue;
         hipStream_t s = e->stream;
         if (fork && op.lane > 0) {
             const int ln = op.lane - 1;
@@ -1117,7 +1171,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         }
         case OP_CONV: {
             ConvArgs a;
-            fill_conv_args(e, op, first, count, a);
+            fill_conv_args(e, op, first, count, a, !materialize);
             const ConvCfg &cc = (count == 1 && stream_share(e, e->cfg.num_slots) > 1) ? op.cfg_one : op.cfg;
             if (!run_conv(op, cc, a, count, s)) return fail(IRMV_ERR_ARG, std::string("no conv kernel for ") + op.kname + " (" + op.layer + ")");
             break;
@@ -1342,9 +1396,7 @@ static int read_tensor_f32(irmv_engine *e, const Tensor &t, int slot, std::vecto
 // them first runs the stand-alone layers the fused kernels cover, on the slot's current device frame.
 static int materialize_fused(irmv_engine *e, int slot)
 {
-    bool any = false;
-    for (const Op &op : e->ops) any = any || op.fused_away;
-    if (!any) return IRMV_OK;
+    if (e->lazy_tensors.empty()) return IRMV_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
     TRY(irmv_engine_wait(e));
     TRY(enqueue_step(e, slot, 1, 0x20000000u, false, nullptr));
@@ -1409,7 +1461,7 @@ extern "C" int irmv_engine_read_tap(irmv_engine *e, int slot, const char *name, 
     const Tensor &t = e->tensors[it->second];
     shape[0] = t.H; shape[1] = t.W; shape[2] = t.C;
     if (!nhwc) return IRMV_OK;
-    if (t.name == "input" || t.name == "0" || t.name == "model.2.cat" || t.name == "model.2.tmp") TRY(materialize_fused(e, slot));
+    if (e->lazy_tensors.count(t.name)) TRY(materialize_fused(e, slot));
     std::vector<float> v;
     TRY(read_tensor_f32(e, t, slot, v));
     memcpy(nhwc, v.data(), v.size() * 4);
@@ -1462,7 +1514,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
             memset(&st, 0, sizeof st);
             snprintf(st.name, sizeof st.name, "%s", (count == 1 && stream_share(e, e->cfg.num_slots) > 1 && op.kind == OP_CONV) ? op.kname_one : op.kname);
             snprintf(st.layer, sizeof st.layer, "%s", op.layer.c_str());
-            st.flops = op.flops * count;
+            st.flops = (op.flops + (op.fuse_next >= 0 ? e->ops[op.fuse_next].flops : 0.0)) * count;
             st.bytes = op.bytes * count;
             st.ms = ms;
         }

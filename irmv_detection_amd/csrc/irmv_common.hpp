@@ -104,6 +104,12 @@ struct ConvArgs {
     int cout_pad;       // multiple of 16
     int ksteps;
     int pair;           // weight rows packed with the paired-tile channel permutation
+    // optional trailing 1x1 conv fused into the epilogue of the LDS 3x3 kernel (Detect-head finals: bias only, fp32
+    // out): this conv's activated fp16 output never leaves the registers.  n2 = 16-row tiles of the 1x1 (0 = none).
+    const half_t *w2;   // direct-family packing of the 1x1 [tile][k-step][64][8], Cin = this conv's 64 channels
+    const float *bias2;
+    float *out2;
+    int out2_ld, n2;
 };
 
 struct ConvCfg { int ks, stride, mt, nt; bool cin16; int act; bool out_f32; bool lds; int ipw; };   // ipw: images per workgroup (LDS family)
@@ -112,7 +118,7 @@ bool launch_conv(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 const char *conv_cfg_name(const ConvCfg &cfg, char *buf, int n);
 // LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt
 size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max);
-bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s);
+bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s);   // a.n2 > 0: fused 1x1 (needs stride 1, nt 4, cout 64)
 
 // SPPF pooling chain: slice 0 (C ch) of [B][H][W][4C] -> slices 1..3 (5x5, 9x9, 13x13 max)
 void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s);

@@ -265,7 +265,7 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 // ---------------------------------------------------------------------------
 constexpr int kPixStride = 96;  // bytes per staged pixel (32 ch fp16 + pad)
 
-template <int STRIDE, int MT, int NT, bool TILE2D>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -350,6 +350,14 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
     }
     const half8 *wsrc = reinterpret_cast<const half8 *>(wl) + (size_t)nblk * chunks * (9 * NT * 64);
 
+    // fused trailing 1x1 (N2 > 0): its A fragments stay in registers for the whole workgroup
+    half8 W2[N2 > 0 ? N2 : 1][2];
+    if constexpr (N2 > 0) {
+        const half8 *w2 = reinterpret_cast<const half8 *>(a.w2) + lane;
+#pragma unroll
+        for (int t2 = 0; t2 < N2; t2++) { W2[t2][0] = w2[(t2 * 2 + 0) * 64]; W2[t2][1] = w2[(t2 * 2 + 1) * 64]; }
+    }
+
     half8 rp[PMAX], rw[WPT];
     const size_t img_stride = (size_t)a.Hin * a.Win * a.s0.ld;
     int l_im = 0, l_chunk = 0;   // loader position: one (image, chunk) step ahead of the MFMAs
@@ -392,6 +400,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
             if (mv[mt]) {
                 const size_t m = (size_t)im * HWo + mloc[mt];
                 if constexpr (NT % 2 == 0) {   // pair-packed (host guarantees): 8 contiguous channels per lane
+                    half8 ov[NT / 2];
 #pragma unroll
                     for (int u = 0; u < NT / 2; u++) {
                         const int c0 = (nt0 / 2 + u) * 32 + g * 8;
@@ -408,10 +417,23 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
 #pragma unroll
                             for (int i = 0; i < 8; i++) vals[i] += (float)rv[i];
                         }
-                        half8 o;
 #pragma unroll
-                        for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
-                        *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = o;
+                        for (int i = 0; i < 8; i++) ov[u][i] = (half_t)vals[i];
+                        if constexpr (N2 == 0) *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = ov[u];
+                    }
+                    if constexpr (N2 > 0) {
+                        // With the paired-tile packing lane (g, r) now holds channels u*32 + 8g + [0, 8) of pixel r: exactly the
+                        // B fragment of k-step u of a 1x1 conv over these 64 channels.  Same operands, same k order as the
+                        // stand-alone 1x1 kernel reading this tensor back from memory.
+#pragma unroll
+                        for (int t2 = 0; t2 < N2; t2++) {
+                            f32x4 c2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][0], ov[0], c2, 0, 0, 0);
+                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][1], ov[1], c2, 0, 0, 0);
+                            const int co = t2 * 16 + g * 4;
+                            *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) =
+                                (f32x4){c2[0] + a.bias2[co], c2[1] + a.bias2[co + 1], c2[2] + a.bias2[co + 2], c2[3] + a.bias2[co + 3]};
+                        }
                     }
                 } else {
                     const int t = nt0;
@@ -511,16 +533,16 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
     return g.bytes;
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2>
 static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int ipw, const LdsGeom &g, hipStream_t s)
 {
     static bool attr_set = false;   // one flag per instantiation
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int groups = (batch + ipw - 1) / ipw;
-    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
                        wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch);
 }
 
@@ -529,10 +551,22 @@ bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, con
     const LdsGeom g = lds_geom(a, stride, mt, nt);
     if (!g.bytes) return false;
     if (ipw < 1) ipw = 1;
+    if (a.n2 > 0) {   // fused trailing 1x1: the workgroup must own all 64 channels of every pixel
+        if (stride != 1 || nt != 4 || a.cout_pad != 64 || !a.pair || a.res) return false;
+#define IRMV_LDS_F(MT_, N2_)                                                                   \
+        if (mt == MT_ && a.n2 == N2_) {                                                        \
+            if (g.tile2d) launch_lds_inst<1, MT_, 4, true, N2_>(a, wl, batch, ipw, g, s);      \
+            else launch_lds_inst<1, MT_, 4, false, N2_>(a, wl, batch, ipw, g, s);              \
+            return true;                                                                       \
+        }
+        IRMV_LDS_F(1, 1) IRMV_LDS_F(2, 1) IRMV_LDS_F(4, 1) IRMV_LDS_F(1, 4) IRMV_LDS_F(2, 4) IRMV_LDS_F(4, 4)
+#undef IRMV_LDS_F
+        return false;
+    }
 #define IRMV_LDS(ST_, MT_, NT_)                                                                \
     if (stride == ST_ && mt == MT_ && nt == NT_) {                                             \
-        if (g.tile2d) launch_lds_inst<ST_, MT_, NT_, true>(a, wl, batch, ipw, g, s);                \
-        else launch_lds_inst<ST_, MT_, NT_, false>(a, wl, batch, ipw, g, s);                        \
+        if (g.tile2d) launch_lds_inst<ST_, MT_, NT_, true, 0>(a, wl, batch, ipw, g, s);                \
+        else launch_lds_inst<ST_, MT_, NT_, false, 0>(a, wl, batch, ipw, g, s);                        \
         return true;                                                                           \
     }
     IRMV_LDS(1, 1, 1) IRMV_LDS(1, 2, 1) IRMV_LDS(1, 4, 1)

@@ -353,7 +353,8 @@ def test_tile_choice_is_bitwise_neutral(blob, frame0):
 ])
 def test_fused_kernels_are_bitwise_identical(blob, monkeypatch, size, net, mode, rot, swap, fused):
     """preprocess + model.0 + model.1 in one kernel (k_front.hip) and model.2 in one kernel (k_c2f.hip) == the
-    seven separate kernels, bit for bit."""
+    seven separate kernels, bit for bit; likewise the Detect branches' final 1x1 convs computed in the epilogue of the
+    preceding 3x3 (k_conv.hip, N2 > 0)."""
     rng = np.random.default_rng(11)
     img = rng.integers(0, 256, (size[1], size[0], 3), dtype=np.uint8)
     img[: size[1] // 2] = frames.synthetic_frame(3, size[0], size[1])[: size[1] // 2]
@@ -361,14 +362,17 @@ def test_fused_kernels_are_bitwise_identical(blob, monkeypatch, size, net, mode,
     for env in ("1", "0"):
         monkeypatch.setenv("IRMV_FUSED_FRONT", env)
         monkeypatch.setenv("IRMV_FUSED_C2F", env)
+        monkeypatch.setenv("IRMV_FUSED_HEAD", env)
         with YoloEngine(None, size, weights_blob=blob, net_size=net, resize_mode=mode, rotate180=rot, swap_rb=swap) as e:
             names = [st["name"] for st in e.profile(0, 1)]
             assert ("front_fused" in names) == (env == "1" and fused)
             assert ("c2f2_fused" in names) == (env == "1")
+            assert any(n.endswith("+1x1") for n in names) == (env == "1")       # Detect finals inside the 3x3 epilogue
             _load(e, 0, img)
             e.detect()
             got.append((e.read_tap("1", 0).copy(), e.read_head(0).copy(), e.read_input(0).copy(), e.read_tap("0", 0).copy(),
-                        e.read_tap("2", 0).copy(), e.read_tap("model.2.cat", 0).copy()))
+                        e.read_tap("2", 0).copy(), e.read_tap("model.2.cat", 0).copy(), e.read_tap("22.cv2.0.1", 0).copy(),
+                        e.read_tap("22.cv3.2.1", 0).copy()))
     for a, b in zip(got[0], got[1]):
         assert np.array_equal(a, b)
     assert np.abs(got[0][0]).max() > 0.1
