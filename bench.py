@@ -175,26 +175,40 @@ def main():
             for st in run:
                 a = agg.setdefault(st["name"], dict(n=0, ms=0.0, flops=0.0, bytes=0.0))
                 a["n"] += 1; a["ms"] += st["ms"]; a["flops"] += st["flops"]; a["bytes"] += st["bytes"]
-        dom_name, dom = max(((k, v) for k, v in agg.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
+        # dominant kernel = the symbol with the largest summed duration in a step.  Its bound follows from its own
+        # arithmetic intensity (algorithmic FLOPs / algorithmic bytes of its launches) against the
+        # ridge of the chip, 2.5 PFLOP/s / 8 TB/s = 312 FLOP/B: below the ridge the roofline ceiling is the HBM line.
+        dom_name, dom = max(((k, v) for k, v in agg.items() if v["bytes"] > 0), key=lambda kv: kv[1]["ms"])
         avg_ms = dom["ms"] / dom["n"]
-        achieved = dom["flops"] / dom["n"] / (avg_ms * 1e-3) / 1e12
+        tflops = dom["flops"] / dom["n"] / (avg_ms * 1e-3) / 1e12
+        gbs_dom = dom["bytes"] / dom["n"] / (avg_ms * 1e-3) / 1e9
+        ai = dom["flops"] / dom["bytes"]
+        ridge = PEAK_FP16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
         conv_ms = sum(v["ms"] for k, v in agg.items() if v["flops"] > 0) / len(prof_runs)
         conv_fl = sum(v["flops"] for k, v in agg.items() if v["flops"] > 0) / len(prof_runs)
-        pre = agg.get("preprocess")
+        pre_name = "preprocess" if "preprocess" in agg else "front_fused"   # fused: preprocess + model.0 + model.1 in one kernel
+        pre = agg.get(pre_name)
         # HBM traffic of that kernel from the separate rocprofv3 --pmc passes (scripts/collect_traffic.py), if collected
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as tf:
                 traffic = (json.load(tf).get(dom_name) or {}).get("hbm_bytes_per_launch")
-        roofline = dict(bound="mfma", kernel=dom_name, launches_per_step=dom["n"] // len(prof_runs),
-                        avg_launch_ms=round(avg_ms, 5), achieved=round(achieved, 3), peak=PEAK_FP16_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP16_TFLOPS, 5), traffic=traffic,
+        if ai >= ridge:
+            roofline = dict(bound="mfma", achieved=round(tflops, 3), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
+                            frac=round(tflops / PEAK_FP16_TFLOPS, 5))
+        else:
+            roofline = dict(bound="hbm", achieved=round(gbs_dom, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=round(gbs_dom / PEAK_HBM_GBS, 5))
+        roofline.update(traffic=traffic, kernel=dom_name, launches_per_step=dom["n"] // len(prof_runs),
+                        avg_launch_ms=round(avg_ms, 5), algorithmic_bytes_per_launch=round(dom["bytes"] / dom["n"]),
+                        algorithmic_flops_per_launch=round(dom["flops"] / dom["n"]), arithmetic_intensity=round(ai, 1),
+                        kernel_tflops=round(tflops, 3), kernel_gbs=round(gbs_dom, 1),
                         all_conv_tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
                         step_kernel_ms_eager=round(sum(v["ms"] for v in agg.values()) / len(prof_runs), 4))
         if pre:
             gbs = pre["bytes"] / pre["n"] / (pre["ms"] / pre["n"] * 1e-3) / 1e9
-            roofline["preprocess_hbm"] = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+            roofline["preprocess_hbm"] = dict(kernel=pre_name, bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                               frac=round(gbs / PEAK_HBM_GBS, 4), avg_launch_ms=round(pre["ms"] / pre["n"], 5))
         fps = world * B * args.steps / dt_max
         out = {

@@ -72,8 +72,8 @@ typedef struct irmv_engine_cfg {
     const void *weights_blob;  /* .irmw image in host memory, or in device memory if weights_on_device */
     uint64_t weights_bytes;
     int32_t weights_on_device; /* 1: weights_blob is a device pointer (e.g. filled by an RCCL broadcast) */
-    int32_t num_streams;       /* HIP streams a multi-slot submit() is spread over (0 = default 2); independent
-                                  sub-batches on separate streams fill each other's launch gaps and tails */
+    int32_t num_streams;       /* HIP streams a multi-slot submit() is spread over (0 = default 1): with more, independent
+                                  sub-batches are replayed as concurrent graphs (helps small batches, costs at large ones) */
     /* Source of the four armor points PnP consumes.  The reference obtains them by classical CV inside
      * each bbox (IrmDetector::extract_armors, src/irm_detector.cpp:292-355); a pose-style model carries them
      * in a keypoint head.  IRMV_POINTS_AUTO picks the keypoint head when the model has one. */

@@ -344,7 +344,9 @@ static int add_conv(irmv_engine *e, const std::string &layer, SegRef s0, SegRef 
     conv_cfg_name(op.cfg, op.kname, sizeof op.kname);
     conv_cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one);
     op.flops = 2.0 * op.Hout * op.Wout * (double)l->cout * l->cin * l->k * l->k;
-    op.bytes = 2.0 * ((double)Hin * Win * l->cin / ((s0.shift || s1.shift) ? 1.0 : 1.0)) +
+    // algorithmic bytes: every input element once (a half-resolution segment = the tensor that exists, not its upsampled
+    // image), the output once, the weights once
+    op.bytes = 2.0 * ((double)(Hin >> s0.shift) * (Win >> s0.shift) * s0.C + (double)(Hin >> s1.shift) * (Win >> s1.shift) * s1.C) +
                (double)op.Hout * op.Wout * l->cout * (ot.f32 ? 4.0 : 2.0) + 2.0 * l->cout * l->cin * l->k * l->k;
     int rc = pack_conv(e, *l, op);
     if (rc) return rc;
@@ -445,7 +447,7 @@ static int build_engine(irmv_engine *e)
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
     }
     { const char *f = getenv("IRMV_FORK_HEAD"); e->fork_head = f && f[0] == '1'; }
-    e->num_streams = c.num_streams > 0 ? c.num_streams : 2;
+    e->num_streams = c.num_streams > 0 ? c.num_streams : 1;
     if (const char *ns = getenv("IRMV_STREAMS")) e->num_streams = atoi(ns);
     e->num_streams = std::max(1, std::min({e->num_streams, 8, c.num_slots}));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));

@@ -47,7 +47,7 @@ struct Conv0Args {
 void launch_conv0(const Conv0Args &a, hipStream_t s);
 
 // fused front: preprocess + model.0.conv + model.1.conv (k_front.hip)
-constexpr int kFrontTileY = 8, kFrontTileX = 16;   // model.1 output tile of one workgroup
+constexpr int kFrontTileY = 4, kFrontTileX = 16;   // model.1 output tile of one workgroup
 constexpr int kFrontStageMax = 128 * 1024;         // most LDS the tile's source region may take (else: the three kernels)
 struct FrontArgs {
     const uint8_t *src;   // [B][sh][sw][3]

@@ -29,6 +29,7 @@ constexpr int TY = kFrontTileY, TX = kFrontTileX;   // model.1 output tile
 constexpr int C0H = 2 * TY + 1, C0W = 2 * TX + 1;    // model.0 outputs it needs
 constexpr int C0HALF = (C0W + 1) / 2;                // columns per parity plane
 constexpr int INH = 4 * TY + 3, INW = 4 * TX + 3;    // net-input pixels those need
+constexpr int MTC = TY / 4;                          // model.1 output rows per wave
 constexpr int INP = INW + 1;                         // row pitch (pixels); the extra column stays zero
 }  // namespace
 
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs a)
 
     // ---- C: model.1.conv: 8 x 16 outputs x 32 channels; Cin = 16, so a k-step of 32 spans two taps ----
     {
-        f32x4 acc[2][2];
+        f32x4 acc[MTC][2];
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++)
+        for (int mt = 0; mt < MTC; mt++)
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -198,17 +199,17 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs a)
         for (int ks = 0; ks < 5; ks++) {
             const int tap = 2 * ks + (g >> 1);
             const int kh = tap / 3, kw = tap - kh * 3;
-            half8 B[2];
+            half8 B[MTC];
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
+            for (int mt = 0; mt < MTC; mt++) {
                 B[mt] = zero8;
                 if (tap < 9) {
-                    const int ly = 2 * (2 * wave + mt) + kh, lx = 2 * r + kw;
+                    const int ly = 2 * (MTC * wave + mt) + kh, lx = 2 * r + kw;
                     B[mt] = *reinterpret_cast<const half8 *>(s_c0 + (size_t)((ly * 2 + (lx & 1)) * C0HALF + (lx >> 1)) * 16 + 8 * (g & 1));
                 }
             }
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+            for (int mt = 0; mt < MTC; mt++)
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[ks][nt], B[mt], acc[mt][nt], 0, 0, 0);
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs a)
 #pragma unroll
             for (int i = 0; i < 8; i++) bias1[i] = a.b1[g * 8 + i];
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
-                const int oy = oy0 + 2 * wave + mt;
+            for (int mt = 0; mt < MTC; mt++) {
+                const int oy = oy0 + MTC * wave + mt;
                 if (oy >= W1) continue;
                 float vals[8];
 #pragma unroll
