@@ -193,7 +193,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as tf:
-                traffic = (json.load(tf).get(dom_name) or {}).get("hbm_bytes_per_launch")
+                import re
+                traffic = (json.load(tf).get(re.sub(r"_i\d+", "", dom_name)) or {}).get("hbm_bytes_per_launch")
         if ai >= ridge:
             roofline = dict(bound="mfma", achieved=round(tflops, 3), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                             frac=round(tflops / PEAK_FP16_TFLOPS, 5))

@@ -9,14 +9,15 @@ import collections, csv, json, re, sys
 
 def internal_name(sym):
     """kernel symbol -> the name bench.py / irmv_engine_profile report"""
-    m = re.search(r"conv3x3_lds_kernelILi(\d)ELi(\d)ELi(\d)E", sym) or re.search(r"conv3x3_lds_kernel<(\d), (\d), (\d)>", sym)
-    if m:
-        return f"conv3x3s{m.group(1)}_lds_mt{m.group(2)}_nt{m.group(3)}"
+    m = (re.search(r"conv3x3_lds_kernel<(\d), (\d), (\d), (true|false), (\d)>", sym) or
+         re.search(r"conv3x3_lds_kernelILi(\d)ELi(\d)ELi(\d)ELb([01])ELi(\d)E", sym))
+    if m:   # images-per-workgroup is a launch argument, not part of the symbol: the "_iN" suffix of the bench name is dropped
+        return f"conv3x3s{m.group(1)}_lds_mt{m.group(2)}_nt{m.group(3)}" + ("+1x1" if m.group(5) != "0" else "")
     m = re.search(r"conv_mfma_kernel<(\d), (\d), (\d), (\d), (true|false), (\d), (true|false)>", sym)
     if m:
         ks, st, mt, nt, c16, act, f32 = m.groups()
         return f"conv{ks}x{ks}s{st}_mt{mt}_nt{nt}" + ("_c16" if c16 == "true" else "") + ("_f32" if f32 == "true" else "")
-    for k, v in (("preprocess_kernel", "preprocess"), ("conv0_kernel", "conv0_mfma"), ("sppf_pool", "sppf_pool"), ("decode_kernel", "decode"), ("nms_pnp_kernel", "nms_pnp")):
+    for k, v in (("front_kernel", "front_fused"), ("c2f2_kernel", "c2f2_fused"), ("light_extract_kernel", "light_extract"), ("preprocess_kernel", "preprocess"), ("conv0_kernel", "conv0_mfma"), ("sppf_pool", "sppf_pool"), ("decode_kernel", "decode"), ("nms_pnp_kernel", "nms_pnp")):
         if k in sym:
             return v
     return sym
@@ -30,13 +31,19 @@ def load(path):
 
 
 f, w = load(sys.argv[1]), load(sys.argv[2])
-out = {}
+acc = {}
 for k in f:
     if "irmv" not in k:
         continue
-    fs = sum(f[k]) / len(f[k])
-    ws = sum(w[k]) / len(w[k]) if k in w else 0.0
-    out[internal_name(k)] = dict(symbol=k, launches=len(f[k]), fetch_kib_raw=round(fs, 1), write_kib=round(ws, 1),
-                  hbm_bytes_per_launch=int((2.0 * fs + ws) * 1024))
+    a = acc.setdefault(internal_name(k), dict(symbols=[], n=0, fetch=0.0, write=0.0))   # several symbols can share a bench name
+    a["symbols"].append(k)
+    a["n"] += len(f[k])
+    a["fetch"] += sum(f[k])
+    a["write"] += sum(w.get(k, [])) * (len(f[k]) / max(len(w.get(k, [])), 1))
+out = {}
+for name, a in acc.items():
+    fs, ws = a["fetch"] / a["n"], a["write"] / a["n"]
+    out[name] = dict(symbols=sorted(a["symbols"]), launches=a["n"], fetch_kib_raw=round(fs, 1), write_kib=round(ws, 1),
+                     hbm_bytes_per_launch=int((2.0 * fs + ws) * 1024))
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print(f"{len(out)} kernels -> {sys.argv[3]}")
