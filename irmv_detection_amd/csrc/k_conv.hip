@@ -265,8 +265,12 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 // ---------------------------------------------------------------------------
 constexpr int kPixStride = 96;  // bytes per staged pixel (32 ch fp16 + pad)
 
+// 16-byte patch pieces a thread stages per chunk (registers are reserved for all of them): a stride-1 2-D block is at
+// most (16 MT + 2) x 18 pixels, the other schemes stage full-width rows or stride-2 patches.
+constexpr int lds_pmax(int stride, int mt, bool tile2d) { return (tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12; }
+
 template <int STRIDE, int MT, int NT, bool TILE2D, int N2>
-__global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvArgs a, const half
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 
     // staging plan: element e -> (patch pixel, 16-byte quarter); weights: 9*NT*64 half8 per chunk
-    constexpr int PMAX = 12;                      // patch 16-B pieces per thread (host guarantees the fit)
+    constexpr int PMAX = lds_pmax(STRIDE, MT, TILE2D);   // patch 16-B pieces per thread (host guarantees the fit)
     constexpr int WPT = (9 * NT * 64 + 255) / 256; // weight half8 per thread
     const int n_pe = PR * PW * 4;
     const float inv_pw = 1.0f / (float)PW;
@@ -518,7 +522,7 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt)
         pr = (rows - 1) * stride + 3;
         pw = a.Win + 2;
     }
-    if ((size_t)pr * pw * 4 > 12 * 256) return g;               // staging plan: at most 12 pieces per thread
+    if ((size_t)pr * pw * 4 > (size_t)lds_pmax(stride, mt, g.tile2d) * 256) return g;   // staging plan: pieces per thread
     g.patch_bytes = pr * pw * kPixStride;
     const size_t bytes = (size_t)g.patch_bytes + (size_t)9 * nt * 1024;
     if (bytes > 80 * 1024) return g;                            // two or more workgroups per CU
