@@ -12,8 +12,9 @@
 // One workgroup per detection.  The frame stays in HBM (no 3.9 MB D2H of the
 // rotated image as on the reference's CPU path): the 180-degree rotation is folded
 // into the pixel fetch.  Thresholding and the per-contour geometry run lane-
-// parallel; the Suzuki-Abe border following is sequential by nature and runs on one
-// lane per detection.  Scratch is bounded (label pool per frame, 1024 contours and
+// parallel; the Suzuki-Abe raster scan runs on one wave per detection (transitions found
+// 64 pixels at a time, the sequential state walked over them), the border following
+// itself on one lane.  Scratch is bounded (label pool per frame, 1024 contours and
 // points_cap contour points per detection); a detection that exhausts any of it gets
 // armor_valid = -1 -- "no answer" -- never a truncated, silently different result.
 #include "irmv_common.hpp"
@@ -22,49 +23,74 @@
 namespace irmv {
 
 constexpr int kLblPos = 2, kLblNeg = -126;
-__device__ const int kDX[16] = {1, 1, 0, -1, -1, -1, 0, 1, 1, 1, 0, -1, -1, -1, 0, 1};
-__device__ const int kDY[16] = {0, -1, -1, -1, 0, 1, 1, 1, 0, -1, -1, -1, 0, 1, 1, 1};
+// Freeman direction s (0 = east, counter-clockwise in image coordinates) -> (dx, dy), from 2-bit fields: a table in
+// memory would put two dependent loads into every step of the border following
+__device__ __forceinline__ int dir_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }   // 1, 1, 0, -1, -1, -1, 0, 1
+__device__ __forceinline__ int dir_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }   // 0, -1, -1, -1, 0, 1, 1, 1
 
 struct LightRec { float top[2], bottom[2], center[2]; double length; int ok; };
 
+// The label image is addressed through an address-space-typed pointer (LDS for ROIs that fit, else global): the
+// border following and the scan are chains of dependent accesses, and a generic pointer would make every one of them a
+// flat access that waits on both the LDS and the vector-memory counter.
+using lds_i8 = __attribute__((address_space(3))) signed char;
+using glb_i8 = __attribute__((address_space(1))) signed char;
+
 // Border following from the outer-border start (x0, y0) of the padded label image; emits the
 // CHAIN_APPROX_SIMPLE points in ROI coordinates.  Returns the number of points (counted past cap).
-__device__ int trace_border(signed char *img, int step, int x0, int y0, short *pts, int cap)
+template <typename P>
+__device__ int trace_border(P *img, int step, int x0, int y0, short *pts, int cap)
 {
+    // all eight neighbours of the current pixel are fetched together (one memory latency per border pixel instead of one
+    // per probe); the direction search runs on the resulting bit mask and the next pixel's own label rides along
+    const int d0 = 1, d1 = 1 - step, d2 = -step, d3 = -1 - step, d4 = -1, d5 = step - 1, d6 = step, d7 = step + 1;
+    unsigned long long nv = 0;   // the eight neighbour labels, one byte each
+    auto neighbours = [&](const P *c) -> unsigned {
+        const unsigned n0 = (unsigned char)c[d0], n1 = (unsigned char)c[d1], n2 = (unsigned char)c[d2], n3 = (unsigned char)c[d3];
+        const unsigned n4 = (unsigned char)c[d4], n5 = (unsigned char)c[d5], n6 = (unsigned char)c[d6], n7 = (unsigned char)c[d7];
+        nv = (unsigned long long)(n0 | (n1 << 8) | (n2 << 16) | (n3 << 24)) | ((unsigned long long)(n4 | (n5 << 8) | (n6 << 16) | (n7 << 24)) << 32);
+        return (n0 != 0) | ((n1 != 0) << 1) | ((n2 != 0) << 2) | ((n3 != 0) << 3) | ((n4 != 0) << 4) | ((n5 != 0) << 5) | ((n6 != 0) << 6) |
+               ((n7 != 0) << 7);
+    };
     int n = 0;
-    signed char *i0 = img + (size_t)y0 * step + x0;
-    int s = 4, s_end = 4;
-    signed char *i1;
-    do {
-        s = (s - 1) & 7;
-        i1 = i0 + kDY[s] * step + kDX[s];
-    } while (*i1 == 0 && s != s_end);
-    if (s == s_end) {
+    P *i0 = img + (size_t)y0 * step + x0;
+    // clockwise from direction 3 (3, 2, 1, 0, 7, 6, 5, 4): first non-zero neighbour; none (direction 4, the left one, is
+    // background at an outer-border start) = a single-pixel component
+    unsigned nz = neighbours(i0);
+    int s = -1;
+    for (int k = 0; k < 8; k++) {
+        const int dir = (3 - k) & 7;
+        if (nz & (1u << dir)) { s = dir; break; }
+    }
+    if (s < 0 || s == 4) {
         *i0 = (signed char)kLblNeg;
         if (n < cap) { pts[0] = (short)(x0 - 1); pts[1] = (short)(y0 - 1); }
         return 1;
     }
-    signed char *i3 = i0, *i4;
+    P *const i1 = i0 + dir_dy(s) * step + dir_dx(s);
+    P *i3 = i0, *i4;
     int px = x0, py = y0, prev_s = s ^ 4;
+    int cur = 1;   // label of i3: the start pixel is unmarked foreground
     for (;;) {
-        s_end = s;
-        for (;;) {
-            ++s;
-            i4 = i3 + kDY[s] * step + kDX[s];
-            if (*i4 != 0) break;
-        }
-        s &= 7;
+        const int s_end = s;
+        // counter-clockwise from s + 1: first non-zero neighbour of i3 (there is one: we came from it)
+        const unsigned rot = ((nz | (nz << 8)) >> (s + 1)) & 0xffu;
+        s = (s + 1 + (__ffs((int)rot) - 1)) & 7;
+        i4 = i3 + dir_dy(s) * step + dir_dx(s);
+        const int next = (int)(signed char)((nv >> (8 * s)) & 0xffull);   // label of i4 as just read
         if ((unsigned)(s - 1) < (unsigned)s_end) *i3 = (signed char)kLblNeg;
-        else if (*i3 == 1) *i3 = (signed char)kLblPos;
+        else if (cur == 1) *i3 = (signed char)kLblPos;
         if (s != prev_s) {
             if (n < cap) { pts[2 * n] = (short)(px - 1); pts[2 * n + 1] = (short)(py - 1); }
             n++;
             prev_s = s;
         }
-        px += kDX[s]; py += kDY[s];
+        px += dir_dx(s); py += dir_dy(s);
         if (i4 == i0 && i3 == i1) break;
         i3 = i4;
+        cur = next;
         s = (s + 4) & 7;
+        nz = neighbours(i3);
     }
     return n;
 }
@@ -74,72 +100,102 @@ __device__ __forceinline__ int cross_i(const short *o, const short *a, const sho
     return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0]);   // |coords| < 2^12: fits int32
 }
 
-// minAreaRect of one contour (points sorted in place, hull built in `hull`), then Light + gating.
-__device__ void contour_to_light(short *p, int n, short *hull, const LightArgs &a, float min_x, float min_y, LightRec &L)
+// minAreaRect of one contour, then Light + gating -- executed by a whole wave (all 64 lanes call it together).
+// p: the contour's n points (sorted and de-duplicated in place); scratch: room for 2n points (sort buffer, then hull).
+// Same arithmetic as oracle/orc_light.c: the sort is a rank sort and every hull edge's bounding rectangle is measured
+// by its own lane, but each number is produced by the same operations, and the winner is the first minimal edge.
+__device__ void contour_to_light(short *p, int n, short *scratch, const LightArgs &a, float min_x, float min_y, int lane, LightRec &L)
 {
     L.ok = 0;
-    // sort by (x, y): insertion sort, contours are a few dozen points
-    for (int i = 1; i < n; i++) {
-        const short x = p[2 * i], y = p[2 * i + 1];
-        int j = i;
-        while (j > 0 && (p[2 * (j - 1)] > x || (p[2 * (j - 1)] == x && p[2 * (j - 1) + 1] > y))) {
-            p[2 * j] = p[2 * (j - 1)]; p[2 * j + 1] = p[2 * (j - 1) + 1];
-            j--;
+    // 1. sort by (x, y): rank of a point = points with a smaller key, plus equal keys before it
+    short *sorted = scratch + 2 * (size_t)n;
+    for (int i = lane; i < n; i += 64) {
+        const int xi = p[2 * i], yi = p[2 * i + 1];
+        const int ki = (xi << 16) | (yi & 0xffff);
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const int kj = ((int)p[2 * j] << 16) | ((int)p[2 * j + 1] & 0xffff);
+            rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
         }
-        p[2 * j] = x; p[2 * j + 1] = y;
+        sorted[2 * rank] = (short)xi; sorted[2 * rank + 1] = (short)yi;
     }
-    int m = 0;
-    for (int i = 0; i < n; i++) {
-        if (m && p[2 * (m - 1)] == p[2 * i] && p[2 * (m - 1) + 1] == p[2 * i + 1]) continue;
-        p[2 * m] = p[2 * i]; p[2 * m + 1] = p[2 * i + 1]; m++;
-    }
-    float c[8];
-    if (m == 1) {
-        for (int i = 0; i < 4; i++) { c[2 * i] = p[0]; c[2 * i + 1] = p[1]; }
-    } else if (m == 2) {
-        c[0] = p[0]; c[1] = p[1]; c[2] = p[0]; c[3] = p[1]; c[4] = p[2]; c[5] = p[3]; c[6] = p[2]; c[7] = p[3];
-    } else {
-        int k = 0;
-        for (int i = 0; i < m; i++) {
-            while (k >= 2 && cross_i(hull + 2 * (k - 2), hull + 2 * (k - 1), p + 2 * i) <= 0) k--;
-            hull[2 * k] = p[2 * i]; hull[2 * k + 1] = p[2 * i + 1]; k++;
+    __threadfence_block();
+    short *hull = scratch;
+    float c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int h = 0, special = 1;   // special: corners already final (degenerate contours)
+    if (lane == 0) {
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            if (m && p[2 * (m - 1)] == sorted[2 * i] && p[2 * (m - 1) + 1] == sorted[2 * i + 1]) continue;
+            p[2 * m] = sorted[2 * i]; p[2 * m + 1] = sorted[2 * i + 1]; m++;
         }
-        for (int i = m - 2, t = k + 1; i >= 0; i--) {
-            while (k >= t && cross_i(hull + 2 * (k - 2), hull + 2 * (k - 1), p + 2 * i) <= 0) k--;
-            hull[2 * k] = p[2 * i]; hull[2 * k + 1] = p[2 * i + 1]; k++;
-        }
-        const int h = k - 1;
-        if (h == 2) {
-            c[0] = hull[0]; c[1] = hull[1]; c[2] = hull[0]; c[3] = hull[1]; c[4] = hull[2]; c[5] = hull[3]; c[6] = hull[2]; c[7] = hull[3];
+        if (m == 1) {
+            for (int i = 0; i < 4; i++) { c[2 * i] = p[0]; c[2 * i + 1] = p[1]; }
+        } else if (m == 2) {
+            c[0] = p[0]; c[1] = p[1]; c[2] = p[0]; c[3] = p[1]; c[4] = p[2]; c[5] = p[3]; c[6] = p[2]; c[7] = p[3];
         } else {
-            double best = 1e300, bc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < h; i++) {
-                const short *pa = hull + 2 * i, *pb = hull + 2 * ((i + 1) % h);
-                double ux = pb[0] - pa[0], uy = pb[1] - pa[1];
-                const double len = sqrt(ux * ux + uy * uy);
-                ux /= len; uy /= len;
-                double smin = 1e300, smax = -1e300, tmin = 1e300, tmax = -1e300;
-                for (int j = 0; j < h; j++) {
-                    const double dx = hull[2 * j] - pa[0], dy = hull[2 * j + 1] - pa[1];
-                    const double s = dx * ux + dy * uy, t = -dx * uy + dy * ux;
-                    if (s < smin) smin = s;
-                    if (s > smax) smax = s;
-                    if (t < tmin) tmin = t;
-                    if (t > tmax) tmax = t;
-                }
-                const double area = (smax - smin) * (tmax - tmin);
-                if (area < best) {
-                    best = area;
-                    const double sx[4] = {smin, smax, smax, smin}, tx[4] = {tmin, tmin, tmax, tmax};
-                    for (int q = 0; q < 4; q++) {
-                        bc[2 * q] = pa[0] + sx[q] * ux - tx[q] * uy;
-                        bc[2 * q + 1] = pa[1] + sx[q] * uy + tx[q] * ux;
-                    }
-                }
+            int k = 0;
+            for (int i = 0; i < m; i++) {
+                while (k >= 2 && cross_i(hull + 2 * (k - 2), hull + 2 * (k - 1), p + 2 * i) <= 0) k--;
+                hull[2 * k] = p[2 * i]; hull[2 * k + 1] = p[2 * i + 1]; k++;
             }
-            for (int q = 0; q < 8; q++) c[q] = (float)bc[q];
+            for (int i = m - 2, t = k + 1; i >= 0; i--) {
+                while (k >= t && cross_i(hull + 2 * (k - 2), hull + 2 * (k - 1), p + 2 * i) <= 0) k--;
+                hull[2 * k] = p[2 * i]; hull[2 * k + 1] = p[2 * i + 1]; k++;
+            }
+            h = k - 1;
+            if (h == 2) {
+                c[0] = hull[0]; c[1] = hull[1]; c[2] = hull[0]; c[3] = hull[1]; c[4] = hull[2]; c[5] = hull[3]; c[6] = hull[2]; c[7] = hull[3];
+            } else {
+                special = 0;
+            }
         }
     }
+    __threadfence_block();
+    h = __shfl(h, 0);
+    special = __shfl(special, 0);
+    if (!special) {
+        // 2. one hull edge per lane: area of the bounding rectangle aligned with it
+        auto measure = [&](int i, double &ux, double &uy, double &smin, double &smax, double &tmin, double &tmax) {
+            const short *pa = hull + 2 * i, *pb = hull + 2 * ((i + 1) % h);
+            ux = pb[0] - pa[0]; uy = pb[1] - pa[1];
+            const double len = sqrt(ux * ux + uy * uy);
+            ux /= len; uy /= len;
+            smin = 1e300; smax = -1e300; tmin = 1e300; tmax = -1e300;
+            for (int j = 0; j < h; j++) {
+                const double dx = hull[2 * j] - pa[0], dy = hull[2 * j + 1] - pa[1];
+                const double sv = dx * ux + dy * uy, tv = -dx * uy + dy * ux;
+                if (sv < smin) smin = sv;
+                if (sv > smax) smax = sv;
+                if (tv < tmin) tmin = tv;
+                if (tv > tmax) tmax = tv;
+            }
+        };
+        double best = 1e300;
+        int bi = 0x7fffffff;
+        for (int i = lane; i < h; i += 64) {
+            double ux, uy, smin, smax, tmin, tmax;
+            measure(i, ux, uy, smin, smax, tmin, tmax);
+            const double area = (smax - smin) * (tmax - tmin);
+            if (area < best) { best = area; bi = i; }
+        }
+        for (int off = 32; off; off >>= 1) {   // first edge of minimal area, as the sequential `area < best` scan picks it
+            const double ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0 && bi < h) {
+            double ux, uy, smin, smax, tmin, tmax;
+            measure(bi, ux, uy, smin, smax, tmin, tmax);
+            const short *pa = hull + 2 * bi;
+            const double sx[4] = {smin, smax, smax, smin}, tx[4] = {tmin, tmin, tmax, tmax};
+            for (int q = 0; q < 4; q++) {
+                c[2 * q] = (float)(pa[0] + sx[q] * ux - tx[q] * uy);
+                c[2 * q + 1] = (float)(pa[1] + sx[q] * uy + tx[q] * ux);
+            }
+        }
+    }
+    if (lane != 0) return;
     // Light(box): corners sorted by y, top / bottom mid-points, length, width, tilt (armor.hpp:14-27)
     float q[4][2];
     for (int i = 0; i < 4; i++) { q[i][0] = c[2 * i]; q[i][1] = c[2 * i + 1]; }
@@ -160,6 +216,85 @@ __device__ void contour_to_light(short *p, int n, short *hull, const LightArgs &
     if (!(a.light_min_ratio < ratio && ratio < a.light_max_ratio && tilt < a.light_max_angle)) return;
     L.center[0] += min_x; L.center[1] += min_y; L.top[0] += min_x; L.top[1] += min_y; L.bottom[0] += min_x; L.bottom[1] += min_y;
     L.ok = 1;
+}
+
+// Raster scan + border following of one ROI by ONE wave (all 64 lanes call it).
+//
+// The sequential scan (oracle/orc_light.c) acts only where a pixel's label differs from its left neighbour's, and of
+// its state only one thing is ever tested: whether the pixel `lnbd_x` points at carries the positive border mark.
+// lnbd_x moves to x when the pixel entered is marked, and to x - 1 when a positively marked pixel is left for
+// background; a border is started at an unmarked foreground pixel entered from background iff the last such event
+// in the row was not "positive".  So per 64-pixel block three ballots (start candidates, positive events, negative
+// events) and a few scalar bit operations reproduce every decision of the scan; only accepted starts are walked
+// (lane 0 follows the border), after which the labels to the right are re-read because they now carry marks.
+template <typename P>
+__device__ void scan_external(P *img, int step, int rw, int rh, int lane, short *pts, int points_cap, int *s_start, int *s_nfound, int *s_toolarge)
+{
+    int nfound = 0, npts = 0;
+    for (int y = 1; y <= rh; y++) {
+        P *row = img + (size_t)y * step;
+        bool last_pos = false;   // label[lnbd_x] > 0 (lnbd_x starts on the zero border)
+        for (int cx = 1; cx <= rw + 1; cx += 256) {
+            // lane L owns pixels cx + L + 64 k (k = 0..3): four consecutive 64-pixel blocks, all loads issued together
+            int cur[4], left[4];
+            auto load_labels = [&]() {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int x = cx + lane + 64 * k;
+                    cur[k] = row[min(x, rw + 1)];
+                    left[k] = row[min(x, rw + 1) - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (cx + lane + 64 * k > rw + 1) { cur[k] = 0; left[k] = 0; }
+            };
+            load_labels();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned long long cand = __ballot(cur[k] == 1 && left[k] == 0);
+                unsigned long long ev_pos = __ballot(cur[k] == kLblPos || (cur[k] == 0 && left[k] == kLblPos));
+                unsigned long long ev_neg = __ballot(cur[k] == kLblNeg);
+                while (cand) {
+                    const int bit = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const unsigned long long below = (1ull << bit) - 1ull;
+                    const unsigned long long e = (ev_pos | ev_neg) & below;
+                    const bool pos = e ? (((ev_pos & below) >> (63 - __clzll((long long)e))) & 1ull) != 0 : last_pos;
+                    if (pos) continue;   // inside a component that has already been followed: not an outer border
+                    const int xx = cx + bit + 64 * k;
+                    const bool keep = nfound < kLightMaxContours;
+                    const int room = keep ? points_cap - npts : 0;
+                    int n = 0;
+                    if (lane == 0) {
+                        short dummy[2];
+                        n = trace_border(img, step, xx, y, room > 0 ? pts + 2 * (size_t)npts : dummy, room > 0 ? room : 0);
+                    }
+                    n = __shfl(n, 0);
+                    if (keep) {
+                        if (lane == 0) s_start[nfound] = npts;
+                        npts += n;
+                        nfound++;
+                    } else {
+                        nfound = kLightMaxContours + 1;
+                    }
+                    __threadfence_block();
+                    load_labels();   // marks to the right (this block and the following ones of the chunk)
+                    const unsigned long long from = ~((2ull << bit) - 1ull);   // positions > bit; the start pixel itself is now an event
+                    cand = __ballot(cur[k] == 1 && left[k] == 0) & from;
+                    ev_pos = __ballot(cur[k] == kLblPos || (cur[k] == 0 && left[k] == kLblPos));
+                    ev_neg = __ballot(cur[k] == kLblNeg);
+                }
+                const unsigned long long e = ev_pos | ev_neg;
+                if (e) last_pos = ((ev_pos >> (63 - __clzll((long long)e))) & 1ull) != 0;
+            }
+        }
+    }
+    if (lane == 0) {
+        const int nf = nfound < kLightMaxContours ? nfound : kLightMaxContours;
+        s_start[nf] = npts;
+        *s_nfound = nf;
+        if (nfound > kLightMaxContours || npts > points_cap) *s_toolarge = 1;
+    }
 }
 
 // cv::Rect(Point2f...) of the clamped bbox (src/irm_detector.cpp:299-307): truncation, not rounding
@@ -184,7 +319,9 @@ __global__ __launch_bounds__(256) void light_extract_kernel(LightArgs a)
     __shared__ int s_nfound, s_toolarge;
     __shared__ unsigned long long s_prefix;
     __shared__ int s_start[kLightMaxContours + 1];
-    __shared__ LightRec s_light[kLightMaxContours];
+    __shared__ LightRec s_top[4][2];   // per wave: the last two gated lights it measured
+    __shared__ int s_topc[4][2], s_nlights;
+    __shared__ __attribute__((aligned(16))) signed char s_img[kLightLdsImage];   // label image of ROIs up to ~200 x 200 (else: the HBM pool)
     const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int ndet = a.num_dets ? min(a.num_dets[b * a.num_dets_stride], a.max_det) : a.n_boxes;
     DevDet *d = a.dets + (size_t)b * a.max_det + j;
@@ -195,7 +332,7 @@ __global__ __launch_bounds__(256) void light_extract_kernel(LightArgs a)
     const int rx = R.rx, ry = R.ry, rw = R.rw, rh = R.rh, step = rw + 2;
     // label image carved from the frame's pool in detection order (deterministic: a full pool drops the
     // lowest-score boxes): offset = sum of the needs of the detections before this one
-    if (tid == 0) { s_prefix = 0ull; s_nfound = 0; }
+    if (tid == 0) { s_prefix = 0ull; s_nfound = 0; s_nlights = 0; }
     __syncthreads();
     unsigned long long mine = 0;
     for (int i = tid; i < j; i += blockDim.x) {
@@ -207,87 +344,84 @@ __global__ __launch_bounds__(256) void light_extract_kernel(LightArgs a)
     const bool fits = !empty && s_prefix + label_bytes(R) <= a.label_pool;
     if (tid == 0) s_toolarge = (!empty && !fits) ? 1 : 0;
     const bool skip = empty || !fits;
-    signed char *img = a.labels + (size_t)b * a.label_pool + (skip ? 0 : s_prefix);
+    // small ROIs keep their label image in LDS (the scan and the border following are latency chains); the pool slice stays
+    // reserved either way, so which detections fit does not depend on this
+    const bool in_lds = !skip && label_bytes(R) <= (unsigned long long)kLightLdsImage;
+    signed char *img = in_lds ? s_img : a.labels + (size_t)b * a.label_pool + (skip ? 0 : s_prefix);
     short *pts = a.points + ((size_t)b * a.max_det + j) * a.points_cap * 2;
     const uint8_t *frame = a.frames + (size_t)b * a.frame_bytes;
 
     if (!skip) {
-        // 1. gray + threshold into the zero-bordered label image (rotation folded into the fetch)
-        const int total = step * (rh + 2);
-        for (int i = tid; i < total; i += blockDim.x) {
-            const int y = i / step, x = i - y * step;
-            signed char v = 0;
-            if (x >= 1 && x <= rw && y >= 1 && y <= rh) {
-                int sx = rx + x - 1, sy = ry + y - 1;
-                if (a.rotate180) { sx = a.cols - 1 - sx; sy = a.rows - 1 - sy; }
-                const uint8_t *px = frame + ((size_t)sy * a.cols + sx) * 3;
+        // 1. gray + threshold into the zero-bordered label image (rotation folded into the fetch): a wave per row,
+        // several pixels of a lane in flight at once (the frame bytes come straight from HBM)
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int y = wave; y < rh + 2; y += 4) {
+            signed char *orow = img + (size_t)y * step;
+            const bool yin = y >= 1 && y <= rh;
+            int sy = ry + y - 1;
+            if (a.rotate180) sy = a.rows - 1 - sy;
+            const uint8_t *frow = frame + (size_t)(yin ? sy : 0) * a.cols * 3;
+#pragma unroll 4
+            for (int x = lane; x < step; x += 64) {
+                const bool inside = yin && x >= 1 && x <= rw;
+                int sx = rx + min(max(x, 1), rw) - 1;          // clamped: the loads below are unconditional, so several pixels' worth are in flight
+                if (a.rotate180) sx = a.cols - 1 - sx;
+                const uint8_t *px = frow + (size_t)sx * 3;
                 const int gray = (px[0] * 3735 + px[1] * 19235 + px[2] * 9798 + (1 << 14)) >> 15;
-                v = gray > a.binary_threshold ? 1 : 0;
+                const signed char v = (inside && gray > a.binary_threshold) ? 1 : 0;
+                orow[x] = v;
             }
-            img[i] = v;
         }
     }
     __syncthreads();
-    // 2. raster scan + border following (one lane)
-    if (!skip && tid == 0) {
-        int nfound = 0, npts = 0;
-        for (int y = 1; y <= rh; y++) {
-            int lnbd_x = 0, prev = 0;
-            signed char *row = img + (size_t)y * step;
-            for (int x = 1; x <= rw + 1; x++) {
-                const int p = row[x];
-                if (p == prev) continue;
-                int is_hole = 0;
-                bool start = true;
-                if (!(prev == 0 && p == 1)) {
-                    if (p != 0 || prev < 1) start = false;
-                    else {
-                        if (prev & -2) lnbd_x = x - 1;
-                        is_hole = 1;
-                    }
-                }
-                if (start && !(is_hole || row[lnbd_x] > 0)) {
-                    if (nfound < kLightMaxContours) {
-                        s_start[nfound] = npts;
-                        const int room = a.points_cap - npts;
-                        npts += trace_border(img, step, x, y, pts + 2 * (size_t)(room > 0 ? npts : 0), room > 0 ? room : 0);
-                        nfound++;
-                    } else {
-                        short dummy[2];
-                        trace_border(img, step, x, y, dummy, 0);
-                        nfound = kLightMaxContours + 1;
-                    }
-                    lnbd_x = x;
-                    prev = row[x];
-                    continue;
-                }
-                prev = p;
-                if (prev & -2) lnbd_x = x;
-            }
-        }
-        s_start[nfound] = npts;
-        s_nfound = nfound < kLightMaxContours ? nfound : kLightMaxContours;
-        if (nfound > kLightMaxContours || npts > a.points_cap) s_toolarge = 1;
+    // 2. raster scan + border following, wave 0.  The scan only ever acts where a pixel's label differs from its left
+    // neighbour's, so the wave finds those transitions 64 pixels at a time (one byte compare per lane + a ballot) and
+    // walks just the set bits with the sequential Suzuki-Abe state (lnbd_x); the walk, its loads and its decisions are
+    // wave-uniform.  A border is followed by lane 0; its marks change labels to the right, so the rest of the chunk is
+    // re-examined afterwards.  Same decisions in the same order as the one-pixel-at-a-time scan of oracle/orc_light.c.
+    if (!skip && tid < 64) {
+        if (in_lds) scan_external((lds_i8 *)s_img, step, rw, rh, tid, pts, a.points_cap, s_start, &s_nfound, &s_toolarge);
+        else scan_external((glb_i8 *)img, step, rw, rh, tid, pts, a.points_cap, s_start, &s_nfound, &s_toolarge);
     }
     __syncthreads();
-    // 3. one lane per contour: minAreaRect -> Light -> gating
+    // 3. a wave per contour: minAreaRect -> Light -> gating.  Contours are visited in discovery order, so the two lights
+    // OpenCV's order (last found first) puts in front are the last two a wave keeps; the waves' pairs are merged below.
     const int nfound = s_nfound;
     const bool pts_ok = !s_toolarge;
-    for (int c = tid; c < nfound; c += blockDim.x) {
-        s_light[c].ok = 0;
-        const int n = s_start[c + 1] - s_start[c];
-        if (n >= 5 && pts_ok) contour_to_light(pts + 2 * (size_t)s_start[c], n, a.hulls + (((size_t)b * a.max_det + j) * a.points_cap + s_start[c]) * 2 * 2, a, min_x, min_y, s_light[c]);
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        short *hulls = a.hulls + ((size_t)b * a.max_det + j) * a.points_cap * 2 * 2;
+        LightRec r0, r1;
+        int c0 = -1, c1 = -1, cnt = 0;
+        r0.ok = r1.ok = 0;
+        for (int c = wave; c < nfound && pts_ok; c += 4) {
+            const int n = s_start[c + 1] - s_start[c];
+            if (n < 5) continue;
+            LightRec L;
+            contour_to_light(pts + 2 * (size_t)s_start[c], n, hulls + (size_t)s_start[c] * 2 * 2, a, min_x, min_y, lane, L);
+            if (lane == 0 && L.ok) { r1 = r0; c1 = c0; r0 = L; c0 = c; cnt++; }
+        }
+        if (lane == 0) {
+            s_top[wave][0] = r0; s_top[wave][1] = r1;
+            s_topc[wave][0] = c0; s_topc[wave][1] = c1;
+            if (cnt) atomicAdd(&s_nlights, cnt);
+        }
     }
     __syncthreads();
-    // 4. first two lights in OpenCV's contour order (last found first) -> Armor -> PnP
+    // 4. first two lights in OpenCV's contour order -> Armor -> PnP
     if (tid == 0) {
-        int nl = 0, total = 0, idx[2] = {0, 0};
-        for (int c = nfound - 1; c >= 0; c--)
-            if (s_light[c].ok) { if (nl < 2) idx[nl++] = c; total++; }
+        const int total = s_nlights;
         int valid = 0, size = 0;
         float kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (total >= 2 && !s_toolarge) {
-            const LightRec &A = s_light[idx[0]], &B = s_light[idx[1]];
+            int w0 = 0, k0 = 0, w1 = 0, k1 = 0, b0 = -1, b1 = -1;   // the two candidates with the highest contour index
+            for (int w = 0; w < 4; w++)
+                for (int k = 0; k < 2; k++) {
+                    const int c = s_topc[w][k];
+                    if (c > b0) { b1 = b0; w1 = w0; k1 = k0; b0 = c; w0 = w; k0 = k; }
+                    else if (c > b1) { b1 = c; w1 = w; k1 = k; }
+                }
+            const LightRec &A = s_top[w0][k0], &B = s_top[w1][k1];
             const LightRec &l = A.center[0] < B.center[0] ? A : B, &r = A.center[0] < B.center[0] ? B : A;
             const double avg = (A.length + B.length) / 2;
             const double cdx = (double)l.center[0] - r.center[0], cdy = (double)l.center[1] - r.center[1];
