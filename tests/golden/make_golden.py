@@ -166,7 +166,29 @@ def pnp_cases():
         json.dump(cases, f)
 
 
+LIGHT_BOXES = [   # xyxy on rm_test.jpg: the armor (two vertical light bars at x 647-654 / 759-767, y 375-404) and non-armors
+    (630, 360, 785, 420), (600, 340, 820, 440), (640.5, 370.2, 770.9, 410.7), (500, 300, 900, 500),   # the armor, tight to loose
+    (630, 360, 700, 420), (700, 360, 785, 420),                 # one light each
+    (630, 388, 785, 420), (630, 360, 785, 390),                 # bars cut by the box edge
+    (430, 690, 680, 740), (640, 690, 680, 715),                 # the three horizontal blobs below: no lights (tilt / ratio gates)
+    (0, 0, 1280, 1024), (-50, -50, 700, 420), (758, 374, 768, 405), (100, 100, 300, 300), (653.2, 380.0, 760.1, 400.0),
+]
+
+
+def light_cases():
+    """Classical extraction (row f1) on the reference's own test image: pins orc_light.c bit for bit."""
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(G, "rm_test.jpg")).convert("RGB"))
+    out = []
+    for b in LIGHT_BOXES:
+        o = oracle.extract_armor(img, np.array(b, np.float32))
+        out.append(dict(box=list(map(float, b)), ok=bool(o["ok"]), size=int(o["size"]) if o["ok"] else -1, n_lights=int(o["n_lights"]),
+                        pts=[float(v) for v in np.asarray(o["pts"]).ravel()] if o["ok"] else []))
+    with open(os.path.join(G, "light_cases.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
 if __name__ == "__main__":
     oracle.build()
-    pre_cases(); rm_test(); net_blocks(); nms_cases(); pnp_cases()
+    pre_cases(); rm_test(); net_blocks(); nms_cases(); pnp_cases(); light_cases()
     print("golden vectors written to", G)

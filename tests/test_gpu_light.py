@@ -116,3 +116,20 @@ def test_classical_points_can_be_forced_on_a_pose_model(blob, frame0):
             arm = e.results(s)
             rot = oracle.rotate180(frames.synthetic_frame(s))
             _compare(arm, rot, np.array([a.bbox_xyxy for a in arm], np.float32))
+
+
+def test_rm_test_jpg_armor_golden_on_gpu(blob, rm_test_image):
+    """The armor in the reference's test image, through irmv_engine_extract_armors: the committed golden, bit for bit,
+    and a plausible pose (a large armor ~1.3 m in front of the reference camera)."""
+    import json
+    from conftest import golden_path
+    cases = json.load(open(golden_path("light_cases.json")))
+    boxes = np.array([c["box"] for c in cases], np.float32)
+    with YoloEngine(None, (1280, 1024), weights_blob=blob, rotate180=False, armor_size=capi.ARMOR_LARGE) as e:
+        e.get_src_image_buffer()[:] = rm_test_image
+        arm = e.extract_armors(boxes)
+    for a, c in zip(arm, cases):
+        assert not a.no_answer and a.valid == c["ok"] and a.n_lights == c["n_lights"], c["box"]
+        if c["ok"]:
+            assert int(a.size) == c["size"] and np.array_equal(a.image_points().ravel(), np.array(c["pts"], np.float32))
+            assert a.pnp_ok and 0.5 < a.tvec[2] < 5.0 and abs(a.tvec[0]) < 1.0 and abs(a.tvec[1]) < 1.0

@@ -102,3 +102,17 @@ def test_gray_and_roi_conventions():
     assert oracle.extract_armor(img, (0, 0, 40, 40))["n_lights"] <= 1
     cs = oracle.find_external_contours(((img.astype(int) @ np.array([3735, 19235, 9798]) + (1 << 14)) >> 15 > 150).astype(np.uint8))
     assert len(cs) == 1
+
+
+def test_rm_test_jpg_armor_golden(rm_test_image):
+    """The reference's own test image holds one armor (two light bars at x 647-654 / 759-767, y 375-404): committed
+    golden of the classical extraction on 15 boxes around it (tests/golden/make_golden.py::light_cases)."""
+    import json
+    from conftest import golden_path
+    cases = json.load(open(golden_path("light_cases.json")))
+    assert sum(c["ok"] for c in cases) == 5
+    for c in cases:
+        o = oracle.extract_armor(rm_test_image, np.array(c["box"], np.float32))
+        assert o["ok"] == c["ok"] and o["n_lights"] == c["n_lights"], c["box"]
+        if c["ok"]:
+            assert int(o["size"]) == c["size"] and np.array_equal(np.asarray(o["pts"], np.float32).ravel(), np.array(c["pts"], np.float32))
