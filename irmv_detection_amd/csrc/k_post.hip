@@ -191,7 +191,7 @@ void launch_pnp_only(const PnpConst &c, const float *pts, int n, int armor_size,
 // The greedy walk is exactly the oracle's: same comparisons, same order.
 // ---------------------------------------------------------------------------
 constexpr int kRankSortMax = 2048;   // capacity of the rank-sort destination
-constexpr int kRankSortUse = 320;    // above this the O(n^2) rank sort loses to the bitonic network
+constexpr int kRankSortUse = 512;    // above this the O(n^2) rank sort loses to the bitonic network
 constexpr int kSupCap = 4096;   // candidates whose intra-block masks are precomputed
 
 __device__ __forceinline__ void wave_lds_sync()
