@@ -93,9 +93,9 @@ __device__ __forceinline__ float dfl_side(const float *l)
     return sj / se;
 }
 
-// Four lanes per (frame, anchor): lane q owns box side q (16 DFL logits, one 64-byte
-// read) and classes 4q..4q+3, so a wave reads 16 whole 320-byte head records and
-// nothing lives in scratch.  The per-side arithmetic is exactly dfl_side().
+// Four lanes per (frame, anchor): lane q owns classes 4q..4q+3 and, for anchors with a
+// candidate, box side q (16 DFL logits, one 64-byte read); nothing lives in scratch.
+// The per-side arithmetic is exactly dfl_side().
 __global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,26 +106,35 @@ __global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
     int ix, iy, s, lbase, lhw, rin;
     anchor_geom(an, a.net, ix, iy, s, lbase, lhw, rin);
     const float *rec = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
-    float l[16];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(rec + 16 * q)[i];
-        l[4 * i] = v[0]; l[4 * i + 1] = v[1]; l[4 * i + 2] = v[2]; l[4 * i + 3] = v[3];
-    }
-    const float d = dfl_side(l);
-    const int lane = threadIdx.x & 63, base = lane & ~3;
-    const float dl = __shfl(d, base), dt = __shfl(d, base + 1), dr = __shfl(d, base + 2), db = __shfl(d, base + 3);
-    if (!live) return;
-    if (q == 0) {
-        const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)s;
-        f32x4 box;
-        box[0] = (ax - dl) * sf;
-        box[1] = (ay - dt) * sf;
-        box[2] = (ax + dr) * sf;
-        box[3] = (ay + db) * sf;
-        reinterpret_cast<f32x4 *>(a.boxes)[quad] = box;
-    }
+    // class logits first (64 of the record's 384 bytes).  The box of an anchor is only ever read for anchors that are
+    // candidates, so the four DFL sides (256 bytes) are fetched and decoded just for those: ~6x less head traffic.
     const f32x4 cl = reinterpret_cast<const f32x4 *>(rec + kClsOff)[q];
+    bool hit = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) hit = hit || (live && 4 * q + i < a.nc && cl[i] > a.logit_thr);
+    const int lane = threadIdx.x & 63, base = lane & ~3;
+    const bool quad_hit = ((__ballot(hit) >> base) & 0xfull) != 0ull;
+    if (quad_hit) {
+        float l[16];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const f32x4 v = reinterpret_cast<const f32x4 *>(rec + 16 * q)[i];
+            l[4 * i] = v[0]; l[4 * i + 1] = v[1]; l[4 * i + 2] = v[2]; l[4 * i + 3] = v[3];
+        }
+        const float d = dfl_side(l);
+        // the four lanes of a quad are either all here or all not: shuffles inside the branch see live sources
+        const float dl = __shfl(d, base), dt = __shfl(d, base + 1), dr = __shfl(d, base + 2), db = __shfl(d, base + 3);
+        if (live && q == 0) {
+            const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)s;
+            f32x4 box;
+            box[0] = (ax - dl) * sf;
+            box[1] = (ay - dt) * sf;
+            box[2] = (ax + dr) * sf;
+            box[3] = (ay + db) * sf;
+            reinterpret_cast<f32x4 *>(a.boxes)[quad] = box;
+        }
+    }
+    if (!live) return;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int c = 4 * q + i;

@@ -16,7 +16,7 @@ ms = np.array([[r[i]["ms"] for i in range(n)] for r in runs]).min(0)
 tot = ms.sum()
 print(f"B={B} sum of kernel times {tot*1e3:.1f} us")
 rows = sorted(range(n), key=lambda i: -ms[i])
-for i in rows[:45]:
+for i in rows[:int(os.environ.get("TOP", "45"))]:
     st = runs[0][i]
     tf = st["flops"] / (ms[i] * 1e-3) / 1e12 if st["flops"] else 0
     print(f"{st['layer']:22s} {st['name']:28s} {ms[i]*1e3:8.1f} us  {tf:7.1f} TF/s  {st['bytes']/(ms[i]*1e-3)/1e9:8.0f} GB/s")
