@@ -714,11 +714,15 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(half_t *buf, int batch, 
 
 void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s)
 {
-    // widest channel slab whose four [H*W][CW] fp16 images fit in LDS
+    // Channel slab of a workgroup: its four [H*W][CW] fp16 images must fit in LDS.  A slab is read as CW * 2 contiguous
+    // bytes per pixel out of a 4 C * 2-byte row, so wide slabs use the memory system better (8 channels = 16 of every
+    // 1024 bytes); narrow slabs give more workgroups.  Widest slab that still leaves ~3 workgroups per CU, else 8.
     int cw = 0;
-    // (narrow slabs: more workgroups, and several fit per CU)
-    for (int c = 8; c <= 32; c <<= 1)
-        if (C % c == 0 && (size_t)4 * H * W * c * 2 <= 150 * 1024) { cw = c; break; }
+    auto fits = [&](int c) { return C % c == 0 && (size_t)4 * H * W * c * 2 <= 150 * 1024; };
+    for (int c = 32; c >= 8 && !cw; c >>= 1)
+        if (fits(c) && (long)batch * (C / c) >= 768) cw = c;
+    for (int c = 8; c <= 32 && !cw; c <<= 1)   // few frames: the narrowest slab = the most workgroups
+        if (fits(c)) cw = c;
     if (cw) {
         const size_t lds = (size_t)4 * H * W * cw * 2;
         static bool attr_set = false;
