@@ -447,7 +447,7 @@ static int build_engine(irmv_engine *e)
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
     }
     { const char *f = getenv("IRMV_FORK_HEAD"); e->fork_head = f && f[0] == '1'; }
-    e->num_streams = c.num_streams > 0 ? c.num_streams : 1;
+    e->num_streams = c.num_streams > 0 ? c.num_streams : 2;
     if (const char *ns = getenv("IRMV_STREAMS")) e->num_streams = atoi(ns);
     e->num_streams = std::max(1, std::min({e->num_streams, 8, c.num_slots}));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));
