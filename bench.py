@@ -207,6 +207,18 @@ def main():
                         kernel_tflops=round(tflops, 3), kernel_gbs=round(gbs_dom, 1),
                         all_conv_tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 3),
                         step_kernel_ms_eager=round(sum(v["ms"] for v in agg.values()) / len(prof_runs), 4))
+        # the five symbols with the largest summed duration, each against its own roofline (same rule as above)
+        step_ms = sum(v["ms"] for v in agg.values())
+        top = []
+        for k, v in sorted(((k, v) for k, v in agg.items() if v["bytes"] > 0), key=lambda kv: -kv[1]["ms"])[:5]:
+            k_ai = v["flops"] / v["bytes"]
+            k_tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            k_gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            top.append(dict(kernel=k, share_of_kernel_time=round(v["ms"] / step_ms, 4), launches_per_step=v["n"] // len(prof_runs),
+                            arithmetic_intensity=round(k_ai, 1), bound="mfma" if k_ai >= ridge else "hbm",
+                            frac=round(k_tf / PEAK_FP16_TFLOPS if k_ai >= ridge else k_gb / PEAK_HBM_GBS, 4),
+                            tflops=round(k_tf, 1), gbs=round(k_gb, 1)))
+        roofline["top_kernels"] = top
         if pre:
             gbs = pre["bytes"] / pre["n"] / (pre["ms"] / pre["n"] * 1e-3) / 1e9
             roofline["preprocess_hbm"] = dict(kernel=pre_name, bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
