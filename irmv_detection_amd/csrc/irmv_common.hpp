@@ -165,6 +165,7 @@ struct PostArgs {
 void launch_decode(const PostArgs &a, int batch, hipStream_t s);
 void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s);
 // ---- classical light extraction (k_light.hip) -------------
+constexpr int kLightLdsPoints = 256;         // contours up to this many points are sorted / hulled in LDS
 constexpr int kLightLdsImage = 40 * 1024;   // padded label images up to this many bytes live in LDS
 constexpr int kLightMaxContours = 1024;   // contours per ROI; more -> armor_valid = -1 (no answer), never a truncated one
 

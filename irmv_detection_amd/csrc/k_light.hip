@@ -33,6 +33,13 @@ struct LightRec { float top[2], bottom[2], center[2]; double length; int ok; };
 // The label image is addressed through an address-space-typed pointer (LDS for ROIs that fit, else global): the
 // border following and the scan are chains of dependent accesses, and a generic pointer would make every one of them a
 // flat access that waits on both the LDS and the vector-memory counter.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 using lds_i8 = __attribute__((address_space(3))) signed char;
 using glb_i8 = __attribute__((address_space(1))) signed char;
 
@@ -95,7 +102,8 @@ __device__ int trace_border(P *img, int step, int x0, int y0, short *pts, int ca
     return n;
 }
 
-__device__ __forceinline__ int cross_i(const short *o, const short *a, const short *b)
+template <typename S>
+__device__ __forceinline__ int cross_i(const S *o, const S *a, const S *b)
 {
     return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0]);   // |coords| < 2^12: fits int32
 }
@@ -104,11 +112,12 @@ __device__ __forceinline__ int cross_i(const short *o, const short *a, const sho
 // p: the contour's n points (sorted and de-duplicated in place); scratch: room for 2n points (sort buffer, then hull).
 // Same arithmetic as oracle/orc_light.c: the sort is a rank sort and every hull edge's bounding rectangle is measured
 // by its own lane, but each number is produced by the same operations, and the winner is the first minimal edge.
-__device__ void contour_to_light(short *p, int n, short *scratch, const LightArgs &a, float min_x, float min_y, int lane, LightRec &L)
+template <typename S>
+__device__ void contour_to_light(S *p, int n, S *scratch, const LightArgs &a, float min_x, float min_y, int lane, LightRec &L)
 {
     L.ok = 0;
     // 1. sort by (x, y): rank of a point = points with a smaller key, plus equal keys before it
-    short *sorted = scratch + 2 * (size_t)n;
+    S *sorted = scratch + 2 * (size_t)n;
     for (int i = lane; i < n; i += 64) {
         const int xi = p[2 * i], yi = p[2 * i + 1];
         const int ki = (xi << 16) | (yi & 0xffff);
@@ -120,7 +129,8 @@ __device__ void contour_to_light(short *p, int n, short *scratch, const LightArg
         sorted[2 * rank] = (short)xi; sorted[2 * rank + 1] = (short)yi;
     }
     __threadfence_block();
-    short *hull = scratch;
+    wave_lds_sync();
+    S *hull = scratch;
     float c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int h = 0, special = 1;   // special: corners already final (degenerate contours)
     if (lane == 0) {
@@ -152,12 +162,13 @@ __device__ void contour_to_light(short *p, int n, short *scratch, const LightArg
         }
     }
     __threadfence_block();
+    wave_lds_sync();
     h = __shfl(h, 0);
     special = __shfl(special, 0);
     if (!special) {
         // 2. one hull edge per lane: area of the bounding rectangle aligned with it
         auto measure = [&](int i, double &ux, double &uy, double &smin, double &smax, double &tmin, double &tmax) {
-            const short *pa = hull + 2 * i, *pb = hull + 2 * ((i + 1) % h);
+            const S *pa = hull + 2 * i, *pb = hull + 2 * ((i + 1) % h);
             ux = pb[0] - pa[0]; uy = pb[1] - pa[1];
             const double len = sqrt(ux * ux + uy * uy);
             ux /= len; uy /= len;
@@ -187,7 +198,7 @@ __device__ void contour_to_light(short *p, int n, short *scratch, const LightArg
         if (lane == 0 && bi < h) {
             double ux, uy, smin, smax, tmin, tmax;
             measure(bi, ux, uy, smin, smax, tmin, tmax);
-            const short *pa = hull + 2 * bi;
+            const S *pa = hull + 2 * bi;
             const double sx[4] = {smin, smax, smax, smin}, tx[4] = {tmin, tmin, tmax, tmax};
             for (int q = 0; q < 4; q++) {
                 c[2 * q] = (float)(pa[0] + sx[q] * ux - tx[q] * uy);
@@ -251,6 +262,8 @@ __device__ void scan_external(P *img, int step, int rw, int rh, int lane, short 
             load_labels();
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+                if (cx + 64 * k > rw + 1) break;                            // past the ROI
+                if (!__ballot((cur[k] | left[k]) != 0)) continue;          // background only: no candidate, no event
                 unsigned long long cand = __ballot(cur[k] == 1 && left[k] == 0);
                 unsigned long long ev_pos = __ballot(cur[k] == kLblPos || (cur[k] == 0 && left[k] == kLblPos));
                 unsigned long long ev_neg = __ballot(cur[k] == kLblNeg);
@@ -319,6 +332,7 @@ __global__ __launch_bounds__(256) void light_extract_kernel(LightArgs a)
     __shared__ int s_nfound, s_toolarge;
     __shared__ unsigned long long s_prefix;
     __shared__ int s_start[kLightMaxContours + 1];
+    __shared__ short s_cpts[4][2 * kLightLdsPoints * 3 + 4];   // per wave: a contour's points + 2n points of sort / hull scratch
     __shared__ LightRec s_top[4][2];   // per wave: the last two gated lights it measured
     __shared__ int s_topc[4][2], s_nlights;
     __shared__ __attribute__((aligned(16))) signed char s_img[kLightLdsImage];   // label image of ROIs up to ~200 x 200 (else: the HBM pool)
@@ -398,7 +412,18 @@ __global__ __launch_bounds__(256) void light_extract_kernel(LightArgs a)
             const int n = s_start[c + 1] - s_start[c];
             if (n < 5) continue;
             LightRec L;
-            contour_to_light(pts + 2 * (size_t)s_start[c], n, hulls + (size_t)s_start[c] * 2 * 2, a, min_x, min_y, lane, L);
+            if (n <= kLightLdsPoints) {
+                // the sort / hull walks are chains of dependent accesses: contours of ordinary size are measured in LDS
+                using lds_i16 = __attribute__((address_space(3))) short;
+                lds_i16 *lp = (lds_i16 *)s_cpts[wave];
+                const short *gp = pts + 2 * (size_t)s_start[c];
+                for (int i = lane; i < 2 * n; i += 64) lp[i] = gp[i];
+                wave_lds_sync();
+                contour_to_light(lp, n, lp + 2 * kLightLdsPoints, a, min_x, min_y, lane, L);
+                wave_lds_sync();
+            } else {
+                contour_to_light(pts + 2 * (size_t)s_start[c], n, hulls + (size_t)s_start[c] * 2 * 2, a, min_x, min_y, lane, L);
+            }
             if (lane == 0 && L.ok) { r1 = r0; c1 = c0; r0 = L; c0 = c; cnt++; }
         }
         if (lane == 0) {
