@@ -369,21 +369,26 @@ __global__ __launch_bounds__(256) void light_extract_kernel(LightArgs a)
         // 1. gray + threshold into the zero-bordered label image (rotation folded into the fetch): a wave per row,
         // several pixels of a lane in flight at once (the frame bytes come straight from HBM)
         const int wave = tid >> 6, lane = tid & 63;
-        for (int y = wave; y < rh + 2; y += 4) {
-            signed char *orow = img + (size_t)y * step;
-            const bool yin = y >= 1 && y <= rh;
-            int sy = ry + y - 1;
-            if (a.rotate180) sy = a.rows - 1 - sy;
-            const uint8_t *frow = frame + (size_t)(yin ? sy : 0) * a.cols * 3;
-#pragma unroll 4
+        constexpr int RU = 8;   // rows of one wave in flight together
+        for (int y0 = wave; y0 < rh + 2; y0 += 4 * RU) {
             for (int x = lane; x < step; x += 64) {
-                const bool inside = yin && x >= 1 && x <= rw;
-                int sx = rx + min(max(x, 1), rw) - 1;          // clamped: the loads below are unconditional, so several pixels' worth are in flight
+                const bool xin = x >= 1 && x <= rw;
+                int sx = rx + min(max(x, 1), rw) - 1;          // clamped: the loads below are unconditional
                 if (a.rotate180) sx = a.cols - 1 - sx;
-                const uint8_t *px = frow + (size_t)sx * 3;
-                const int gray = (px[0] * 3735 + px[1] * 19235 + px[2] * 9798 + (1 << 14)) >> 15;
-                const signed char v = (inside && gray > a.binary_threshold) ? 1 : 0;
-                orow[x] = v;
+                int gray[RU];
+#pragma unroll
+                for (int r = 0; r < RU; r++) {
+                    const int y = y0 + 4 * r;
+                    int sy = ry + min(max(y, 1), rh) - 1;
+                    if (a.rotate180) sy = a.rows - 1 - sy;
+                    const uint8_t *px = frame + ((size_t)sy * a.cols + sx) * 3;
+                    gray[r] = (px[0] * 3735 + px[1] * 19235 + px[2] * 9798 + (1 << 14)) >> 15;
+                }
+#pragma unroll
+                for (int r = 0; r < RU; r++) {
+                    const int y = y0 + 4 * r;
+                    if (y < rh + 2) img[(size_t)y * step + x] = (xin && y >= 1 && y <= rh && gray[r] > a.binary_threshold) ? 1 : 0;
+                }
             }
         }
     }
