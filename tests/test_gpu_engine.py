@@ -348,6 +348,11 @@ def test_tile_choice_is_bitwise_neutral(blob, frame0):
     ((640, 640), 640, 0, True, False, True),       # BASELINE configs[1]
     ((1280, 1024), 416, 0, True, False, True),     # 104 x 104 output: partial tiles
     ((1920, 1200), 640, 1, True, False, True),     # 3x down-scale: 87 KB source region per tile, one workgroup per CU
+    ((1024, 768), 640, 0, True, False, True),
+    ((1600, 1200), 640, 1, True, False, True),
+    ((644, 480), 640, 0, False, False, True),      # up-scale in x: a tile's source region is narrower than the tile
+    ((1280, 720), 640, 1, False, True, True),      # letterbox bands above and below
+    ((800, 600), 416, 1, True, False, True),
     ((641, 479), 640, 0, True, False, False),      # width not a multiple of 4: falls back to the three kernels
     ((4096, 3000), 640, 0, True, False, False),    # tile's source region larger than the LDS stage: falls back
 ])
