@@ -265,6 +265,17 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 // ---------------------------------------------------------------------------
 constexpr int kPixStride = 96;  // bytes per staged pixel (32 ch fp16 + pad)
 
+// hipFuncSetAttribute is per device: remember, per kernel, on which devices it has been applied
+static bool dev_flag_test_and_set(unsigned long long &mask)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    const bool was = (mask & bit) != 0;
+    mask |= bit;
+    return was;
+}
+
 // 16-byte patch pieces a thread stages per chunk (registers are reserved for all of them): a stride-1 2-D block is at
 // most (16 MT + 2) x 18 pixels, the other schemes stage full-width rows or stride-2 patches.
 constexpr int lds_pmax(int stride, int mt, bool tile2d) { return (tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12; }
@@ -540,11 +551,9 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
 template <int STRIDE, int MT, int NT, bool TILE2D, int N2>
 static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int ipw, const LdsGeom &g, hipStream_t s)
 {
-    static bool attr_set = false;   // one flag per instantiation
-    if (!attr_set) {
+    static unsigned long long attr_done = 0;   // per instantiation: devices whose dynamic-LDS limit has been raised
+    if (!dev_flag_test_and_set(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     const int groups = (batch + ipw - 1) / ipw;
     hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
                        wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch);
@@ -725,11 +734,9 @@ void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s
         if (fits(c)) cw = c;
     if (cw) {
         const size_t lds = (size_t)4 * H * W * cw * 2;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_done = 0;
+        if (!dev_flag_test_and_set(attr_done))
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sppf_pool_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
         hipLaunchKernelGGL(sppf_pool_lds_kernel, dim3(batch * (C / cw)), dim3(256), lds, s, buf, H, W, C, cw);
         return;
     }
