@@ -90,6 +90,33 @@ public:
     return dets_.data();
   }
 
+  // Extension: the node's IrmDetector::extract_armors(get_rotated_image(), bboxes) (reference src/irm_detector.cpp:183,
+  // 292-355) on the GPU, on the frame of the last detect().  One Armor per bbox in which two gated lights were found,
+  // in bbox order, like the reference; `poses`, if given, receives the IPPE pose of each returned armor.
+  std::vector<Armor> extract_armors(const std::vector<bbox> & bboxes, std::vector<irmv_det> * poses = nullptr)
+  {
+    std::vector<Armor> armors;
+    if (bboxes.empty()) return armors;
+    std::vector<float> xyxy;
+    xyxy.reserve(bboxes.size() * 4);
+    for (const auto & b : bboxes) xyxy.insert(xyxy.end(), b.xyxy.begin(), b.xyxy.end());
+    std::vector<irmv_det> out(bboxes.size());
+    if (irmv_engine_extract_armors(engine_, 0, xyxy.data(), static_cast<int>(bboxes.size()), out.data()) != IRMV_OK)
+      throw std::runtime_error(std::string("YoloEngine::extract_armors: ") + irmv_last_error());
+    for (size_t i = 0; i < out.size(); i++) {
+      const irmv_det & d = out[i];
+      if (d.armor_valid != 1) continue;   // no pair of lights (0) or scratch exhausted (-1): the reference emits nothing either
+      Armor a(Light(cv::Point2f(d.kpts[2], d.kpts[3]), cv::Point2f(d.kpts[0], d.kpts[1])),
+              Light(cv::Point2f(d.kpts[4], d.kpts[5]), cv::Point2f(d.kpts[6], d.kpts[7])));
+      a.size = d.armor_size == IRMV_ARMOR_LARGE ? ArmorSize::LARGE : ArmorSize::SMALL;
+      a.armor_class = bboxes[i].class_id;
+      a.confidence = bboxes[i].score;
+      armors.push_back(a);
+      if (poses) poses->push_back(d);
+    }
+    return armors;
+  }
+
   void visualize_bboxes(cv::Mat & image, const std::vector<bbox> & bboxes) const
   {
     if (image.cols != src_image_size_.width || image.rows != src_image_size_.height) {

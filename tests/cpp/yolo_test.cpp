@@ -38,6 +38,13 @@ int main(int argc, char ** argv)
   std::printf("rotated_ok %d\n", int(yolo_engine.get_rotated_image().data[0] == frame[last] && yolo_engine.get_rotated_image().data[last + 2] == frame[2]));
   std::printf("profiling_ms %.4f\n", yolo_engine.get_profiling_time());
 
+  // --- the node's classical armor extraction on the detector's boxes (src/irm_detector.cpp:183), on the GPU ---
+  {
+    std::vector<irmv_det> poses;
+    const auto armors = yolo_engine.extract_armors(bboxes, &poses);
+    std::printf("classical armors %zu of %zu boxes, poses %zu\n", armors.size(), bboxes.size(), poses.size());
+  }
+
   // --- PnP on the first armor, the node's call shape (src/irm_detector.cpp:204-216) ---
   int n = 0;
   const irmv_det * dets = yolo_engine.last_detections(&n);

@@ -61,6 +61,12 @@ def test_reference_test_flow_on_gpu(tmp_path, blob, frame0):
     first = [float(v) for v in re.search(r"bbox 0 (\S+) (\S+) (\S+) (\S+) (\S+)", txt).groups()]
     assert np.allclose(first[:4], bb[0].xyxy, atol=1e-4) and abs(first[4] - bb[0].score) < 1e-5
     assert "rotated_ok 1" in txt
+    m = re.search(r"classical armors (\d+) of (\d+) boxes, poses (\d+)", txt)
+    boxes_xyxy = np.array([b.xyxy for b in bb], np.float32)
+    with YoloEngine(None, (1280, 1024), weights_blob=blob) as e:
+        e.get_src_image_buffer()[:] = frame0
+        n_valid = sum(a.valid for a in e.extract_armors(boxes_xyxy))
+    assert int(m.group(1)) == int(m.group(3)) == n_valid and int(m.group(2)) == len(bb)
     m = re.search(r"pnp ok (\d) fused_ok (\d) worst_diff (\S+) tvec (\S+) (\S+) (\S+)", txt)
     assert m.group(1) == m.group(2) == "1" and float(m.group(3)) < 1e-9        # standalone PnPSolver == fused PnP
     assert np.allclose([float(m.group(i)) for i in (4, 5, 6)], arm[0].tvec, atol=1e-8)
