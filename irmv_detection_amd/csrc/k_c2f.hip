@@ -19,21 +19,18 @@ namespace {
 constexpr int T = kC2fTile;               // output tile (pixels per side)
 constexpr int XW = T + 4, XN = XW * XW;   // block input / y1 region (halo 2)
 constexpr int TW = T + 2, TN = TW * TW;   // bottleneck intermediate region (halo 1)
-constexpr int XP = 80;                    // bytes per pixel of the staged 32-channel input: 64 + 16 pad, so 16
-                                          // consecutive pixels hit 16 distinct 16-byte slots of a 256-byte window
-constexpr int HP = 32;                    // bytes per pixel of the 16-channel planes (conflict-free as they are)
-constexpr int kOffT = 0, kOffY2 = TN * HP;          // t and y2 reuse the input stage once cv1 has consumed it
-static_assert(kOffY2 + T * T * HP <= XN * XP, "t + y2 must fit the input stage");
+constexpr int HP = 32;                    // bytes per pixel of the 16-channel planes (16 consecutive pixels x 2 halves hit
+                                          // 16 distinct 16-byte slots of a 256-byte window: conflict-free ds_read_b128)
 
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 }  // namespace
 
 __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_x[XN * XP];
     __shared__ __attribute__((aligned(16))) uint8_t s_y0[T * T * HP];
     __shared__ __attribute__((aligned(16))) uint8_t s_y1[XN * HP];
-    uint8_t *s_t = s_x + kOffT, *s_y2 = s_x + kOffY2;
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[TN * HP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_y2[T * T * HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
     const int b = blockIdx.y;
@@ -56,29 +53,23 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
     w = reinterpret_cast<const half8 *>(a.w_cv2) + lane;
     const half8 Wc2[2][2] = {{w[0], w[64]}, {w[128], w[192]}};   // [tile][k-step]
 
-    // ---- 0: block input with halo 2 -> LDS (zero outside the image) ----
-    {
-        const half_t *xin = a.x + (size_t)b * S * S * a.x_ld;
-        for (int i = tid; i < XN * 4; i += 256) {
-            const int px = i >> 2, q = i & 3;
-            const int ly = px / XW, lx = px - ly * XW;
-            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            half8 v = zero8;
-            if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S)
-                v = *reinterpret_cast<const half8 *>(xin + ((size_t)gy * S + gx) * a.x_ld + q * 8);
-            *reinterpret_cast<half8 *>(s_x + px * XP + q * 16) = v;
-        }
-    }
-    __syncthreads();
-
     // ---- 1: cv1 (1x1, 32 -> 32, SiLU) on the 20 x 20 region -> y0 (centre only), y1 (whole region) ----
     {
         float bias[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) bias[i] = a.b_cv1[g * 8 + i];
+        const half_t *xin = a.x + (size_t)b * S * S * a.x_ld;
         for (int t = wave; t < XN / 16; t += 4) {
             const int m = t * 16 + r;
-            const half8 B = *reinterpret_cast<const half8 *>(s_x + m * XP + g * 16);
+            // the block input is read exactly once per workgroup, so its B fragments come straight from memory (zero
+            // outside the image)
+            half8 B = zero8;
+            {
+                const int ly = m / XW, lx = m - ly * XW;
+                const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+                if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S)
+                    B = *reinterpret_cast<const half8 *>(xin + ((size_t)gy * S + gx) * a.x_ld + g * 8);
+            }
             f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[0], B, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[1], B, acc1, 0, 0, 0);
