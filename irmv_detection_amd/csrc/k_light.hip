@@ -46,7 +46,7 @@ using glb_i8 = __attribute__((address_space(1))) signed char;
 // Border following from the outer-border start (x0, y0) of the padded label image; emits the
 // CHAIN_APPROX_SIMPLE points in ROI coordinates.  Returns the number of points (counted past cap).
 template <typename P>
-__device__ int trace_border(P *img, int step, int x0, int y0, short *pts, int cap)
+__device__ int trace_border(P *img, int step, int x0, int y0, short *pts, int cap, int max_steps)
 {
     // all eight neighbours of the current pixel are fetched together (one memory latency per border pixel instead of one
     // per probe); the direction search runs on the resulting bit mask and the next pixel's own label rides along
@@ -78,7 +78,9 @@ __device__ int trace_border(P *img, int step, int x0, int y0, short *pts, int ca
     P *i3 = i0, *i4;
     int px = x0, py = y0, prev_s = s ^ 4;
     int cur = 1;   // label of i3: the start pixel is unmarked foreground
-    for (;;) {
+    // A border visits each of its pixels at most four times, so the walk ends within 4 x (image pixels) steps; the bound
+    // only exists so that a corrupted label image could never keep a wave spinning on the GPU.
+    for (int guard = 0; guard < max_steps; guard++) {
         const int s_end = s;
         // counter-clockwise from s + 1: first non-zero neighbour of i3 (there is one: we came from it)
         const unsigned rot = ((nz | (nz << 8)) >> (s + 1)) & 0xffu;
@@ -280,7 +282,7 @@ __device__ void scan_external(P *img, int step, int rw, int rh, int lane, short 
                     int n = 0;
                     if (lane == 0) {
                         short dummy[2];
-                        n = trace_border(img, step, xx, y, room > 0 ? pts + 2 * (size_t)npts : dummy, room > 0 ? room : 0);
+                        n = trace_border(img, step, xx, y, room > 0 ? pts + 2 * (size_t)npts : dummy, room > 0 ? room : 0, 4 * step * (rh + 2) + 16);
                     }
                     n = __shfl(n, 0);
                     if (keep) {
