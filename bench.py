@@ -88,6 +88,18 @@ def main():
     from irmv_detection_amd.engine import DEFAULT_CAMERA_MATRIX, DEFAULT_DIST_COEFFS, YoloEngine
 
     rank, local_rank, world = D.init()
+    # Tile choices: seed the autotuner from the table measured for this build (profiles/r01_tune_cache.txt) so that every
+    # run and every rank replays the same, bitwise-neutral choices; layers missing from it are tuned on the spot.  Each
+    # rank works on its own copy (the engine rewrites the file it is given).
+    if "IRMV_TUNE_CACHE" not in os.environ:
+        seed = os.path.join(ROOT, "profiles", "r01_tune_cache.txt")
+        if os.path.exists(seed):
+            import shutil, tempfile
+            mine = os.path.join(tempfile.gettempdir(), f"irmv_tune_{os.getpid()}.txt")
+            shutil.copyfile(seed, mine)
+            os.environ["IRMV_TUNE_CACHE"] = mine
+            import atexit
+            atexit.register(lambda: os.path.exists(mine) and os.remove(mine))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():

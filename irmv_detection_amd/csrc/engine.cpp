@@ -922,7 +922,7 @@ static int autotune_convs(irmv_engine *e)
                         lds_ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, mt, nt, &pr) > 0;
                     }
             char key[160];
-            snprintf(key, sizeof key, "%d|%d.%d.%d.%d.%d.%d|%dx%d>%dx%d|c%d.%d.%d.%d>%d|ld%d.%d.%d|n%d|%d", e->cfg.device, op.cfg.ks, op.cfg.stride,
+            snprintf(key, sizeof key, "gfx950|%d.%d.%d.%d.%d.%d|%dx%d>%dx%d|c%d.%d.%d.%d>%d|ld%d.%d.%d|n%d|%d", op.cfg.ks, op.cfg.stride,
                      (int)op.cfg.cin16, op.cfg.act, (int)op.cfg.out_f32, (int)lds_ok, a.Hin, a.Win, a.Hout, a.Wout, a.s0.C, a.s1.C, a.s0.shift,
                      a.s1.shift, a.cout_pad, a.s0.ld, a.s1.ld, a.out_ld, counts[pass], (a.res ? 1 : 0) + 2 * a.n2);
             auto hit = g_tune_cache.find(key);
