@@ -31,6 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+METRIC = "end-to-end FPS (preprocess\u2192NMS\u2192PnP) 640\u00d7640 YOLOv8n, 1/2/4/8 MI355X"   # BASELINE.json "metric", verbatim
 PEAK_FP16_TFLOPS = 2500.0      # dense fp16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
@@ -237,7 +238,7 @@ def main():
                                               frac=round(gbs / PEAK_HBM_GBS, 4), avg_launch_ms=round(pre["ms"] / pre["n"], 5))
         fps = world * B * args.steps / dt_max
         out = {
-            "metric": "end-to-end FPS (preprocess->NMS->PnP) 640x640 YOLOv8n",
+            "metric": METRIC,
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
