@@ -30,7 +30,7 @@ extern "C" {
 #define IRMV_ERR_ARG (-1)      /* bad argument / configuration            */
 #define IRMV_ERR_HIP (-2)      /* HIP runtime failure (message has detail) */
 #define IRMV_ERR_MODEL (-3)    /* weight blob missing or not matching      */
-#define IRMV_ERR_OVERFLOW (-4) /* reserved (the candidate list now holds every (anchor, class) pair) */
+#define IRMV_ERR_OVERFLOW (-4) /* reserved, never returned (the candidate list holds every (anchor, class) pair) */
 
 #define IRMV_RESIZE_STRETCH 0   /* reference behaviour: src/yolo_engine.cpp:186-190 */
 #define IRMV_RESIZE_LETTERBOX 1 /* north-star variant */
@@ -156,14 +156,22 @@ uint8_t *irmv_engine_src_buffer(irmv_engine *e, int slot);
  * frame in HBM, and for HBM-resident benchmarking). */
 void *irmv_engine_src_device_buffer(irmv_engine *e, int slot);
 
-#define IRMV_SUBMIT_H2D 1u /* copy pinned slots -> HBM first (async, same stream, ahead of the captured kernels) */
+#define IRMV_SUBMIT_H2D 1u    /* copy pinned slots -> HBM first (async, on the engine's upload stream) */
+#define IRMV_SUBMIT_INLINE 2u /* upload, kernels and download on ONE stream (no cross-stream events): lowest latency for a
+                                 synchronous single-slot call, no copy/compute overlap */
 
-/* Enqueue one step for slots [first, first+count) on the engine's stream:
- * [async H2D of the frames] -> ONE hipGraph {preprocess -> network -> decode ->
- * NMS -> keypoints -> PnP} -> async D2H of the results; returns immediately.  count == 1 is the reference's per-slot
- * detect(); count > 1 batches independent frames through every kernel. */
+/* Enqueue one step for slots [first, first+count) and return immediately:
+ *   upload stream   : async H2D of the frames (IRMV_SUBMIT_H2D)
+ *   compute stream  : ONE hipGraph {preprocess -> network -> decode -> NMS -> keypoints -> PnP}
+ *   download stream : async D2H of the results
+ * chained by events, so the upload of one slot group overlaps the kernels of another -- the dGPU form of the
+ * reference's TripleBuffer hand-off (triple_buffer.hpp:24-40, src/camera.cpp:40-61).  count == 1 is the reference's
+ * per-slot detect(); count > 1 batches independent frames through every kernel.  One thread submits. */
 int irmv_engine_submit(irmv_engine *e, int first_slot, int count, uint32_t flags);
+/* Block until everything submitted so far is done and host-visible. */
 int irmv_engine_wait(irmv_engine *e);
+/* Block until the results of slots [first, first+count) are host-visible; other slots stay in flight. */
+int irmv_engine_wait_slots(irmv_engine *e, int first_slot, int count);
 /* Results of one slot after wait(): up to cap detections, score-descending. */
 int irmv_engine_results(irmv_engine *e, int slot, irmv_det *out, int cap, int *n);
 /* submit(slot, 1, H2D) + wait + results == YoloEngine::detect() (src/yolo_engine.cpp:153-177) */

@@ -3,13 +3,14 @@
 // MI355X-first counterpart of irmv_detection::YoloEngine (reference
 // src/yolo_engine.cpp) and PnPSolver (src/pnp_solver.cpp):
 //   * frame slots are pinned host memory (hipHostMalloc) copied to HBM by an
-//     async memcpy node of the captured step -- the dGPU answer to the
-//     reference's cudaMallocManaged source buffer (:60-61) + TripleBuffer;
+//     async copy on a dedicated upload stream, event-chained to the captured
+//     step (results come back on a download stream of their own) -- the dGPU
+//     answer to the reference's cudaMallocManaged source buffer (:60-61) +
+//     TripleBuffer: slot n+1 uploads while slot n computes;
 //   * one set of weights per device shared by all slots (the reference builds
 //     three full engines, src/irm_detector.cpp:35-38);
-//   * the kernels of a step {preprocess, ~73 conv launches, pool, decode, NMS+PnP}
+//   * the kernels of a step {front, fused C2f blocks, convs, pool, decode, NMS+PnP}
 //     are captured once per (first_slot, count) into a hipGraph (:102-107),
-//     bracketed by the async H2D frame copy and D2H result copy on the same stream,
 //     and `count` independent frames ride through every kernel as the batch
 //     dimension of its GEMM M axis, which is what fills 256 CUs;
 //   * no host work between launch and results except the final struct copy
@@ -23,6 +24,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <set>
 #include <memory>
 #include <string>
@@ -135,6 +137,15 @@ struct GraphKey {
     }
 };
 
+// Events of one submitted slot group [first, first + count): upload done -> compute may start; compute done ->
+// download may start and the device frames may be overwritten; download done -> results are host-visible.
+struct SlotGroup {
+    int first = 0, count = 0;
+    hipEvent_t h2d = nullptr, done = nullptr, out = nullptr;
+    hipStream_t compute = nullptr;   // compute stream of the last submit
+    bool in_flight = false;          // submitted and not yet known complete
+};
+
 struct irmv_engine {
     irmv_engine_cfg cfg{};
     int nc = 0, nk = 0, A = 0, no = 0;
@@ -146,6 +157,12 @@ struct irmv_engine {
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // Detect-branch lanes (only ever used under stream capture)
     hipEvent_t ev_level[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
     bool fork_head = false;   // opt-in (IRMV_FORK_HEAD=1): measured 11 % SLOWER than the linear graph at 16 frames/step
+    // frame hand-off: uploads and downloads ride streams of their own, chained to the compute
+    // streams by one event triple per submitted slot group
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    std::map<std::pair<int, int>, SlotGroup> groups;   // (first, count) -> events of that group's last submit
+    std::vector<SlotGroup *> slot_owner;               // per slot: the group whose submit touched it last
+    bool inline_copies = false;                        // IRMV_INLINE_COPIES=1: round-1 behaviour, copies on the compute stream
     uint8_t *src_host = nullptr;  // pinned [S][frame]
     uint8_t *src_dev = nullptr;   // [S][frame]
     uint8_t *rot_dev = nullptr;   // [frame]
@@ -184,10 +201,29 @@ struct irmv_engine {
     ~irmv_engine();
 };
 
+// Optional allocation log (IRMV_LOG_ALLOC=1): every device / pinned range an engine owns, so that a faulting
+// address reported by the driver can be mapped to a buffer.
+static bool log_alloc() { static const bool on = getenv("IRMV_LOG_ALLOC") != nullptr; return on; }
+static void log_range(const irmv_engine *e, const char *what, const void *p, size_t bytes)
+{
+    if (log_alloc()) fprintf(stderr, "[irmv alloc] engine %p %-18s [%p, %p) %zu bytes\n", (const void *)e, what, p, (const void *)((const char *)p + bytes), bytes);
+}
+
+// Teardown order matters: nothing may be freed while any stream of this engine can still touch it.
+//   1. drain EVERY stream the engine ever enqueued work on (compute, upload, download, capture side lanes);
+//   2. destroy the graph executables (they hold kernel-argument copies pointing into the buffers);
+//   3. free device memory, then pinned host memory;
+//   4. destroy events and streams.
 irmv_engine::~irmv_engine()
 {
     if (cfg.device >= 0) (void)hipSetDevice(cfg.device);
     if (stream) (void)hipStreamSynchronize(stream);
+    for (int i = 0; i < 7; i++)
+        if (extra_streams[i]) (void)hipStreamSynchronize(extra_streams[i]);
+    for (int i = 0; i < 3; i++)
+        if (side[i]) (void)hipStreamSynchronize(side[i]);
+    if (h2d_stream) (void)hipStreamSynchronize(h2d_stream);
+    if (d2h_stream) (void)hipStreamSynchronize(d2h_stream);
     if (dbg_dev) {   // diagnostic: phase cycles of the last nms_pnp launch per slot (100 MHz s_memtime-independent clock64)
         std::vector<long long> h((size_t)cfg.num_slots * 8);
         if (hipMemcpy(h.data(), dbg_dev, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -196,18 +232,28 @@ irmv_engine::~irmv_engine()
                         h[s * 8 + 2] - h[s * 8 + 1], h[s * 8 + 3] - h[s * 8 + 2], h[s * 8 + 4] - h[s * 8 + 3], h[s * 8 + 5], h[s * 8 + 6]);
     }
     for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
+    graphs.clear();
+    if (log_alloc()) fprintf(stderr, "[irmv alloc] engine %p destroy: freeing %zu device ranges\n", (const void *)this, dev_allocs.size());
     for (void *p : dev_allocs) (void)hipFree(p);
+    dev_allocs.clear();
     if (src_host) (void)hipHostFree(src_host);
     if (dets_host) (void)hipHostFree(dets_host);
     if (fout_host) (void)hipHostFree(fout_host);
     if (light_dets_host) (void)hipHostFree(light_dets_host);
-    for (int i = 0; i < 7; i++)
-        if (extra_streams[i]) { (void)hipStreamSynchronize(extra_streams[i]); (void)hipStreamDestroy(extra_streams[i]); }
+    for (auto &kv : groups) {
+        if (kv.second.h2d) (void)hipEventDestroy(kv.second.h2d);
+        if (kv.second.done) (void)hipEventDestroy(kv.second.done);
+        if (kv.second.out) (void)hipEventDestroy(kv.second.out);
+    }
     for (int i = 0; i < 3; i++) {
-        if (side[i]) (void)hipStreamDestroy(side[i]);
         if (ev_level[i]) (void)hipEventDestroy(ev_level[i]);
         if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+        if (side[i]) (void)hipStreamDestroy(side[i]);
     }
+    for (int i = 0; i < 7; i++)
+        if (extra_streams[i]) (void)hipStreamDestroy(extra_streams[i]);
+    if (h2d_stream) (void)hipStreamDestroy(h2d_stream);
+    if (d2h_stream) (void)hipStreamDestroy(d2h_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -218,6 +264,7 @@ static int dev_alloc(irmv_engine *e, void **p, size_t bytes)
 {
     HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
     e->dev_allocs.push_back(*p);
+    log_range(e, "device", *p, bytes ? bytes : 16);
     return IRMV_OK;
 }
 
@@ -451,8 +498,13 @@ static int build_engine(irmv_engine *e)
     if (const char *ns = getenv("IRMV_STREAMS")) e->num_streams = atoi(ns);
     e->num_streams = std::max(1, std::min({e->num_streams, 8, c.num_slots}));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->h2d_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->d2h_stream, hipStreamNonBlocking));
+    { const char *ic = getenv("IRMV_INLINE_COPIES"); e->inline_copies = ic && ic[0] == '1'; }
+    e->slot_owner.assign(S, nullptr);
     e->frame_bytes = (size_t)c.src_width * c.src_height * 3;
     HIP_TRY(hipHostMalloc((void **)&e->src_host, e->frame_bytes * S, hipHostMallocDefault));
+    log_range(e, "pinned src_host", e->src_host, e->frame_bytes * S);
     memset(e->src_host, 0, e->frame_bytes * S);
     TRY(dev_alloc(e, (void **)&e->src_dev, e->frame_bytes * S));
     HIP_TRY(hipMemset(e->src_dev, 0, e->frame_bytes * S));
@@ -638,6 +690,8 @@ static int build_engine(irmv_engine *e)
     HIP_TRY(hipMemset(e->fout_dev, 0, (size_t)S * sizeof(DevFrameOut)));
     HIP_TRY(hipHostMalloc((void **)&e->dets_host, (size_t)S * c.max_det * sizeof(DevDet), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&e->fout_host, (size_t)S * sizeof(DevFrameOut), hipHostMallocDefault));
+    log_range(e, "pinned dets_host", e->dets_host, (size_t)S * c.max_det * sizeof(DevDet));
+    log_range(e, "pinned fout_host", e->fout_host, (size_t)S * sizeof(DevFrameOut));
     memset(e->dets_host, 0, (size_t)S * c.max_det * sizeof(DevDet));
     memset(e->fout_host, 0, (size_t)S * sizeof(DevFrameOut));
     { Op op; op.kind = OP_DECODE; op.layer = "decode"; snprintf(op.kname, sizeof op.kname, "decode");
@@ -658,6 +712,7 @@ static int build_engine(irmv_engine *e)
     TRY(dev_alloc(e, (void **)&e->light_boxes, (size_t)c.max_det * 16));
     TRY(dev_alloc(e, (void **)&e->light_dets_dev, (size_t)c.max_det * sizeof(DevDet)));
     HIP_TRY(hipHostMalloc((void **)&e->light_dets_host, (size_t)c.max_det * sizeof(DevDet), hipHostMallocDefault));
+    log_range(e, "pinned light_dets", e->light_dets_host, (size_t)c.max_det * sizeof(DevDet));
 
     PostArgs &p = e->post;
     p.net = net; p.A = e->A; p.nc = e->nc; p.nk = e->nk;
@@ -832,6 +887,8 @@ extern "C" void *irmv_engine_src_device_buffer(irmv_engine *e, int slot)
 
 // tile choices already measured in this process, keyed by layer shape and batch (engines are created
 // repeatedly in tests and by multi-slot nodes; the kernels and the device do not change in between)
+// Process-wide and shared by every engine on every thread: all accesses hold g_tune_mu.
+static std::mutex g_tune_mu;
 static std::map<std::string, ConvCfg> g_tune_cache;
 static bool g_tune_file_loaded = false;
 
@@ -839,6 +896,7 @@ static bool g_tune_file_loaded = false;
 // replays exactly the tiles of the benchmarked run without the tuning launches in its trace.
 static void tune_cache_load()
 {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
     if (g_tune_file_loaded) return;
     g_tune_file_loaded = true;
     const char *path = getenv("IRMV_TUNE_CACHE");
@@ -857,6 +915,7 @@ static void tune_cache_save()
 {
     const char *path = getenv("IRMV_TUNE_CACHE");
     if (!path) return;
+    std::lock_guard<std::mutex> lk(g_tune_mu);
     std::ofstream f(path);
     for (auto &kv : g_tune_cache) f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << (kv.second.lds ? 1 : 0) << ' ' << kv.second.ipw << '\n';
 }
@@ -925,12 +984,32 @@ static int autotune_convs(irmv_engine *e)
             snprintf(key, sizeof key, "gfx950|%d.%d.%d.%d.%d.%d|%dx%d>%dx%d|c%d.%d.%d.%d>%d|ld%d.%d.%d|n%d|%d", op.cfg.ks, op.cfg.stride,
                      (int)op.cfg.cin16, op.cfg.act, (int)op.cfg.out_f32, (int)lds_ok, a.Hin, a.Win, a.Hout, a.Wout, a.s0.C, a.s1.C, a.s0.shift,
                      a.s1.shift, a.cout_pad, a.s0.ld, a.s1.ld, a.out_ld, counts[pass], (a.res ? 1 : 0) + 2 * a.n2);
-            auto hit = g_tune_cache.find(key);
-            if (hit != g_tune_cache.end() && !verbose) {
-                best_cfg = op.cfg;
-                best_cfg.mt = hit->second.mt; best_cfg.nt = hit->second.nt; best_cfg.lds = hit->second.lds; best_cfg.ipw = hit->second.ipw;
-                best = 0.f;
-            } else
+            // A cached choice (this process, or the IRMV_TUNE_CACHE file) is replayed only if it is a legal tile of THIS
+            // layer at THIS batch: tile shape offered by the family, channel split divides cout, images per workgroup within
+            // the batch, LDS geometry fits, and the fused epilogue's constraints.  Anything else is re-tuned.
+            bool have_hit = false;
+            {
+                std::lock_guard<std::mutex> lk(g_tune_mu);
+                auto hit = g_tune_cache.find(key);
+                if (hit != g_tune_cache.end() && !verbose) {
+                    const ConvCfg &h = hit->second;
+                    const bool pow2 = (h.mt == 1 || h.mt == 2 || h.mt == 4) && (h.nt == 1 || h.nt == 2 || h.nt == 4) && (h.ipw == 1 || h.ipw == 2 || h.ipw == 4);
+                    bool ok = pow2 && op.cout_pad % (16 * h.nt) == 0 && h.ipw <= counts[pass] && h.lds == lds_ok && (!want_fuse || h.nt == 4);
+                    if (ok && h.lds) {
+                        const int li = h.nt == 4 ? 2 : (h.nt == 2 ? 1 : 0);
+                        ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, h.mt, h.nt, nullptr) > 0;
+                    }
+                    if (ok && !h.lds) ok = h.ipw == 1;
+                    if (ok) {
+                        best_cfg = op.cfg;
+                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw;
+                        best = 0.f;
+                        have_hit = true;
+                    } else if (getenv("IRMV_AUTOTUNE_VERBOSE") || getenv("IRMV_TUNE_WARN"))
+                        fprintf(stderr, "[autotune] cached tile for %s rejected (mt %d nt %d lds %d ipw %d): re-tuning\n", key, h.mt, h.nt, (int)h.lds, h.ipw);
+                }
+            }
+            if (!have_hit)
             for (int fam = lds_ok ? 1 : 0; fam <= (lds_ok ? 1 : 0); fam++)
                 for (int mt = 1; mt <= 4; mt *= 2)
                     for (int nt = 1; nt <= 4; nt *= 2)
@@ -959,7 +1038,7 @@ static int autotune_convs(irmv_engine *e)
                         }
                         if (ms < best) { best = ms; best_cfg = c; }
                     }
-            g_tune_cache[key] = best_cfg;
+            { std::lock_guard<std::mutex> lk(g_tune_mu); g_tune_cache[key] = best_cfg; }
             if (pass == 0) { op.cfg = best_cfg; cfg_name(op.cfg, op.kname, sizeof op.kname); }
             else { op.cfg_one = best_cfg; cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
             if (counts[0] == 1) { op.cfg_one = op.cfg; cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
@@ -1197,8 +1276,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     return IRMV_OK;
 }
 
-// The frame upload and the result download bracket the captured kernels as plain
-// async copies on the same stream (pinned memory both ways).
+// Frame upload and result download: plain async copies, pinned memory both ways, on the streams submit_group() picks.
 static int copy_in(irmv_engine *e, int first, int count, hipStream_t st)
 {
     HIP_TRY(hipMemcpyAsync(e->src_dev + (size_t)first * e->frame_bytes, e->src_host + (size_t)first * e->frame_bytes,
@@ -1242,6 +1320,71 @@ static int get_graph(irmv_engine *e, int first, int count, uint32_t flags, bool 
     return IRMV_OK;
 }
 
+static int group_of(irmv_engine *e, int first, int count, SlotGroup **out)
+{
+    const auto key = std::make_pair(first, count);
+    auto it = e->groups.find(key);
+    if (it == e->groups.end()) {
+        SlotGroup g;
+        g.first = first; g.count = count;
+        HIP_TRY(hipEventCreateWithFlags(&g.h2d, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.out, hipEventDisableTiming));
+        it = e->groups.emplace(key, g).first;
+    }
+    *out = &it->second;   // std::map nodes never move
+    return IRMV_OK;
+}
+
+// One slot group through the hand-off pipeline (the dGPU form of the reference's TripleBuffer,
+// include/irmv_detection/triple_buffer.hpp:24-40, whose slots ARE the engines' input memory):
+//
+//   upload stream    [wait: previous step of this group has read its device frames]  H2D frames   -> ev h2d
+//   compute stream   [wait: ev h2d; previous results of this group have left HBM]     hipGraph     -> ev done
+//   download stream  [wait: ev done]                                                  D2H results  -> ev out
+//
+// The three streams only meet at these events, so group B's upload runs under group A's kernels and A's
+// download under B's kernels: with two or more groups in flight the PCIe link and the CUs are busy at once.
+static int submit_group(irmv_engine *e, int f, int c, uint32_t flags, hipStream_t st)
+{
+    hipGraphExec_t ge;
+    TRY(get_graph(e, f, c, 0, false, &ge));
+    SlotGroup *g;
+    TRY(group_of(e, f, c, &g));
+    const bool inl = e->inline_copies || (flags & IRMV_SUBMIT_INLINE);
+    hipStream_t up = inl ? st : e->h2d_stream, down = inl ? st : e->d2h_stream;
+    // slots last used through a different grouping: order behind that group's download
+    SlotGroup *seen[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int s = f; s < f + c; s++) {
+        SlotGroup *o = e->slot_owner[s];
+        e->slot_owner[s] = g;
+        if (!o || o == g || !o->in_flight || o == seen[0] || o == seen[1] || o == seen[2] || o == seen[3]) continue;
+        seen[3] = seen[2]; seen[2] = seen[1]; seen[1] = seen[0]; seen[0] = o;
+        HIP_TRY(hipStreamWaitEvent(up, o->out, 0));
+        if (st != up) HIP_TRY(hipStreamWaitEvent(st, o->out, 0));
+    }
+    if (flags & IRMV_SUBMIT_H2D) {
+        if (g->in_flight && up != g->compute) HIP_TRY(hipStreamWaitEvent(up, g->done, 0));
+        TRY(copy_in(e, f, c, up));
+        if (up != st) {
+            HIP_TRY(hipEventRecord(g->h2d, up));
+            HIP_TRY(hipStreamWaitEvent(st, g->h2d, 0));
+        }
+    }
+    if (g->in_flight && (down != st || g->compute != st)) HIP_TRY(hipStreamWaitEvent(st, g->out, 0));
+    HIP_TRY(hipGraphLaunch(ge, st));
+    if (down != st) {
+        HIP_TRY(hipEventRecord(g->done, st));
+        HIP_TRY(hipStreamWaitEvent(down, g->done, 0));
+    }
+    TRY(copy_out(e, f, c, down));
+    HIP_TRY(hipEventRecord(g->out, down));
+    if (down == st) HIP_TRY(hipEventRecord(g->done, st));
+    g->in_flight = true;
+    g->compute = st;
+    return IRMV_OK;
+}
+
 extern "C" int irmv_engine_submit(irmv_engine *e, int first, int count, uint32_t flags)
 {
     TRY(check_range(e, first, count));
@@ -1254,19 +1397,18 @@ extern "C" int irmv_engine_submit(irmv_engine *e, int first, int count, uint32_t
     for (int f = first; f < first + count; f += share, si++) {
         const int c = std::min(share, first + count - f);
         hipStream_t st = si == 0 ? e->stream : e->extra_streams[si - 1];
-        hipGraphExec_t ge;
-        TRY(get_graph(e, f, c, 0, false, &ge));
-        if (flags & IRMV_SUBMIT_H2D) TRY(copy_in(e, f, c, st));
-        HIP_TRY(hipGraphLaunch(ge, st));
-        TRY(copy_out(e, f, c, st));
+        TRY(submit_group(e, f, c, flags, st));
     }
     return IRMV_OK;
 }
+
+extern "C" int irmv_engine_wait(irmv_engine *e);
 
 extern "C" int irmv_engine_run_post(irmv_engine *e, int first, int count)
 {
     TRY(check_range(e, first, count));
     HIP_TRY(hipSetDevice(e->cfg.device));
+    TRY(irmv_engine_wait(e));
     hipGraphExec_t ge;
     TRY(get_graph(e, first, count, 0, true, &ge));
     HIP_TRY(hipGraphLaunch(ge, e->stream));
@@ -1278,8 +1420,30 @@ extern "C" int irmv_engine_run_post(irmv_engine *e, int first, int count)
 extern "C" int irmv_engine_wait(irmv_engine *e)
 {
     if (!e) return fail(IRMV_ERR_ARG, "engine is null");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->h2d_stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamSynchronize(e->extra_streams[i - 1]));
+    HIP_TRY(hipStreamSynchronize(e->d2h_stream));
+    for (auto &kv : e->groups) kv.second.in_flight = false;
+    return IRMV_OK;
+}
+
+// Block until the results of slots [first, first + count) from their last submit are host-visible; other slots may
+// stay in flight (the consumer side of the TripleBuffer: take the newest finished slot while the next one runs).
+extern "C" int irmv_engine_wait_slots(irmv_engine *e, int first, int count)
+{
+    TRY(check_range(e, first, count));
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    SlotGroup *last = nullptr;
+    for (int s = first; s < first + count; s++) {
+        SlotGroup *o = e->slot_owner[s];
+        if (!o || o == last || !o->in_flight) continue;
+        HIP_TRY(hipEventSynchronize(o->out));
+        // the whole group is done only if this call covers it; otherwise it merely stays marked in flight (harmless)
+        if (o->first >= first && o->first + o->count <= first + count) o->in_flight = false;
+        last = o;
+    }
     return IRMV_OK;
 }
 
@@ -1308,15 +1472,17 @@ extern "C" int irmv_engine_results(irmv_engine *e, int slot, irmv_det *out, int 
         o.reserved = 0;
     }
     *n = k;
-    if (fo.overflow) return fail(IRMV_ERR_OVERFLOW, "more than IRMV_CAND_CAP candidates above score_thr; raise score_thr");
     return IRMV_OK;
 }
 
 extern "C" int irmv_engine_detect(irmv_engine *e, int slot, irmv_det *out, int cap, int *n)
 {
     const auto t0 = std::chrono::high_resolution_clock::now();
-    TRY(irmv_engine_submit(e, slot, 1, IRMV_SUBMIT_H2D));
-    TRY(irmv_engine_wait(e));
+    static const bool inline_detect = [] { const char *v = getenv("IRMV_DETECT_STREAMED"); return !(v && v[0] == '1'); }();
+    // a synchronous single-slot call has nothing to overlap with: upload, graph and download ride ONE stream (no
+    // cross-stream event hops on the latency path).  IRMV_DETECT_STREAMED=1 sends it through the three-stream pipeline.
+    TRY(irmv_engine_submit(e, slot, 1, IRMV_SUBMIT_H2D | (inline_detect ? IRMV_SUBMIT_INLINE : 0u)));
+    TRY(irmv_engine_wait_slots(e, slot, 1));
     const int rc = irmv_engine_results(e, slot, out, cap, n);
     e->last_detect_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
     return rc;
@@ -1499,6 +1665,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
     // command-processor hand-over, which would read as kernel time on these 5-80 us kernels.
     // (Event-record nodes inside a captured graph cannot be read back with hipEventElapsedTime on
     // ROCm 7.2: "invalid resource handle".)
+    TRY(irmv_engine_wait(e));
     std::vector<EvRec> ev;
     TRY(enqueue_step(e, first, count, kProfileRepeat, false, &ev));
     TRY(copy_out(e, first, count));
@@ -1530,12 +1697,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
 struct irmv_pnp {
     int device = 0;
     PnpConst c{};
-    hipStream_t stream = nullptr;                 // stream 0: single-slot detect(), read-backs, profile
-    hipStream_t extra_streams[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // streams 1..num_streams-1
-    int num_streams = 1;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // Detect-branch lanes (only ever used under stream capture)
-    hipEvent_t ev_level[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
-    bool fork_head = false;   // opt-in (IRMV_FORK_HEAD=1): measured 11 % SLOWER than the linear graph at 16 frames/step
+    hipStream_t stream = nullptr;
     float *pts = nullptr;
     double *rvec = nullptr, *tvec = nullptr;
     int32_t *ok = nullptr;

@@ -295,7 +295,8 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     }
 
     if (n_stored <= kRankSortUse) {
-        for (int i = tid; i < n_stored; i += blockDim.x) skeys[i] = gk[i];
+        if (!preloaded)   // after a radix select skeys already holds the selected keys: gk[0..n_stored) would be the wrong ones
+            for (int i = tid; i < n_stored; i += blockDim.x) skeys[i] = gk[i];
         __syncthreads();
         // keys are unique, so "number of keys greater than mine" is a permutation
         const int n8 = (n_stored + 7) & ~7;

@@ -231,12 +231,19 @@ class YoloEngine:
                         image[y1c:y2c + 1, x] = color
 
     # ---- batched / asynchronous extension (MI355X-first surface) ------------------
-    def submit(self, first_slot: int = 0, count: Optional[int] = None, h2d: bool = True) -> None:
+    def submit(self, first_slot: int = 0, count: Optional[int] = None, h2d: bool = True, inline: bool = False) -> None:
+        """Enqueue slots [first_slot, first_slot + count) and return: upload, kernels and download ride three
+        event-chained streams, so the next group's upload overlaps this group's kernels (`inline`: one stream)."""
         count = self.num_slots - first_slot if count is None else count
-        capi.check(self._L.irmv_engine_submit(self._h, first_slot, count, capi.SUBMIT_H2D if h2d else 0))
+        flags = (capi.SUBMIT_H2D if h2d else 0) | (capi.SUBMIT_INLINE if inline else 0)
+        capi.check(self._L.irmv_engine_submit(self._h, first_slot, count, flags))
 
     def wait(self) -> None:
         capi.check(self._L.irmv_engine_wait(self._h))
+
+    def wait_slots(self, first_slot: int, count: int = 1) -> None:
+        """Block until these slots' results are host-visible; other slots stay in flight."""
+        capi.check(self._L.irmv_engine_wait_slots(self._h, first_slot, count))
 
     def results(self, slot: int) -> List[Armor]:
         n = C.c_int(0)

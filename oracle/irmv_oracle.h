@@ -58,6 +58,7 @@ int orc_net_nc(const orc_net *);
 int orc_net_nk(const orc_net *);
 int orc_head_channels(const orc_net *); /* 64 + nc + nk */
 int orc_num_anchors(int net);
+void orc_set_threads(int n);   /* OpenMP threads of orc_net_forward */
 
 /* in_chw f32 [3][net][net] -> head f32 [anchors][64+nc+nk] (levels P3,P4,P5,
  * each row-major).  emulate_fp16 != 0 rounds the input and every stored

@@ -55,6 +55,8 @@ def lib():
         L.orc_net_nk.argtypes = [C.c_void_p]
         L.orc_head_channels.argtypes = [C.c_void_p]
         L.orc_num_anchors.argtypes = [C.c_int]
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads.restype = None
         L.orc_net_forward.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, f32p, C.c_char_p, f32p, i32p]
         L.orc_conv_layer.argtypes = [C.c_void_p, C.c_char_p, f32p, C.c_int, C.c_int, f32p]
         L.orc_expf.argtypes = [C.c_float]

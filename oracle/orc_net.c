@@ -19,6 +19,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ---- fp16 round trip (IEEE binary16, round-to-nearest-even) ------------- */
 static uint16_t f32_to_f16_bits(float f)
@@ -146,6 +149,16 @@ void orc_net_free(orc_net *n)
 int orc_net_nc(const orc_net *n) { return n->nc; }
 int orc_net_nk(const orc_net *n) { return n->nk; }
 int orc_head_channels(const orc_net *n) { return 64 + n->nc + n->nk; }
+/* worker threads of the forward pass (bench.py's cpu_baseline reports the 1-thread and the all-core rate) */
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_anchors(int net) { return (net / 8) * (net / 8) + (net / 16) * (net / 16) + (net / 32) * (net / 32); }
 
 static const struct orc_conv *find_layer(const orc_net *n, const char *name)

@@ -1,0 +1,50 @@
+#!/bin/bash
+# Run GPU stages one after another on the box; a stage that is killed, times out or dies on a signal stops the chain
+# (nothing more is started on a possibly wedged GPU); an ordinary non-zero exit (failed assertion) is recorded and the chain goes on.
+#   gpurun --timeout 1100 -- 'bash scripts/gpu_stage.sh tests layers pmc bench'
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+run() {   # run <name> <timeout s> <cmd...>
+    local name=$1 to=$2; shift 2
+    echo "=== stage $name: $*" | tee -a $O/stages.log
+    timeout -k 10 $to "$@" > $O/$name.log 2>&1
+    local rc=$?
+    echo "=== stage $name exit $rc" | tee -a $O/stages.log
+    tail -n 25 $O/$name.log
+    if [ $rc -ge 124 ]; then echo "stage $name was killed / timed out / crashed: stopping the chain" | tee -a $O/stages.log; exit $rc; fi
+    return 0
+}
+: > $O/stages.log
+for st in "$@"; do
+case $st in
+tests)   run gpu_tests 900 python3 -m pytest tests -m gpu -x -q -rA --durations=15 ;;
+tests_k) run gpu_tests_k 600 python3 -m pytest tests -m gpu -x -q -rA -k "$TESTS_K" ;;
+smoke)   run smoke 300 python3 __graft_entry__.py smoke ;;
+layers)  SLOTS=64 run layers64 300 python3 scripts/prof_layers.py
+         SLOTS=1 TOP=70 run layers1 200 python3 scripts/prof_layers.py ;;
+bench)   run bench 600 python3 bench.py ;;
+benchq)  run benchq 400 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline ;;
+stats)   export IRMV_TUNE_CACHE=$O/tune_cache.txt
+         cd /tmp; export TMPDIR=/tmp
+         IRMV_BENCH_SKIP=latency,h2d run prof_stats 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline
+         cd $R ;;
+pmc)     cd /tmp; export TMPDIR=/tmp
+         IRMV_STREAMS=1 run pmc_a 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_b 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         cd $R
+         python3 scripts/collect_mfma.py $O/mfma.json $O/pmc_a/*/*_counter_collection.csv $O/pmc_b/*/*_counter_collection.csv ;;
+traffic) cd /tmp; export TMPDIR=/tmp
+         IRMV_STREAMS=1 run pmc_f 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_w 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         cd $R
+         python3 scripts/collect_traffic.py $O/pmc_f/*/*_counter_collection.csv $O/pmc_w/*/*_counter_collection.csv $O/traffic.json ;;
+repro)   # the round-1 fault sequence, ONCE, under the profiler that exposed it, with every allocation range logged
+         cd /tmp; export TMPDIR=/tmp
+         IRMV_LOG_ALLOC=1 run repro_prof 300 rocprofv3 --kernel-trace --output-format csv -d $O/repro_prof -- python3 $R/scripts/repro_two_engines.py
+         cd $R ;;
+*)       run "custom_$st" 600 bash -c "$st" ;;
+esac
+done
+echo "=== all stages done" | tee -a $O/stages.log

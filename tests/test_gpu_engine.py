@@ -3,12 +3,18 @@ reference's YoloEngine / PnPSolver interface), against the CPU oracle.
 
 Stated tolerances (DESIGN.md "Parity"):
   preprocess            bit-exact (integer taps; fp16 of v/255 is unique)
-  activations / head    fp16 storage, fp32 accumulate: |d| <= 6e-2 abs on logits of magnitude ~20
+  activations / head    fp16 storage, fp32 accumulate: |d| <= 3e-2 abs on logits of magnitude ~20
                         vs the fp32 oracle; same bound vs the fp16-emulating oracle
   decode / NMS / kpts   bit-exact on identical head tensors (survivor set AND order);
-                        end to end vs the fp32 oracle: >= 90 % of (anchor, class) survivors shared, shared
-                        boxes within 0.06 * stride px, scores within 5e-3, keypoints within 0.12 * stride px
+                        end to end vs the fp32 oracle: survivor set IDENTICAL on the margin fixtures
+                        (tests/golden/margin_cases.json: every decode / NMS decision clear of fp16 noise), boxes
+                        within BOX_TOL(stride) px, scores within 5e-3, keypoints within 0.75 px
   PnP                   fp64: |d rvec|, |d tvec| <= 1e-6
+
+Box tolerance per stride: a head-logit error e moves a DFL side (the expectation over 16 bins) by up to ~e bins =
+e * stride px.  With |e| <= 3e-2 that is 0.24 / 0.48 / 0.96 px at strides 8 / 16 / 32 (fp16-emulating oracle vs fp32
+oracle on the same frames: 0.23 / 0.36 / 0.97), so SURVEY's 0.5 px holds at strides 8 and 16 and cannot hold at 32,
+where the bar is 0.04 bins = 1.28 px.
 """
 import json
 import zlib
@@ -23,7 +29,17 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
-HEAD_TOL = 6e-2
+HEAD_TOL = 3e-2
+KPT_TOL = 0.75
+SCORE_TOL = 5e-3
+
+
+def BOX_TOL(stride):
+    return max(0.5, 0.04 * stride)
+
+
+def _stride(anchor):
+    return 8 if anchor < 6400 else (16 if anchor < 8000 else 32)
 
 
 @pytest.fixture(scope="module")
@@ -192,6 +208,17 @@ def test_more_candidates_than_the_lds_sort_holds(eng):
     eng.results(0)                                      # no overflow error any more
 
 
+@pytest.mark.parametrize("cap", [100, 300, 512, 513, 2048])
+def test_more_candidates_than_the_lds_sort_holds_small_pre_nms_cap(blob, cap):
+    """> 8192 candidates AND pre_nms_cap <= 512: the radix-selected keys go through the rank sort, which must sort the
+    SELECTED keys (round 1 re-read the first K raw keys there).  513 / 2048: the bitonic branch after a select."""
+    rng = np.random.default_rng(33)
+    head = _synthetic_head(rng, 0.15)
+    with YoloEngine(None, (1280, 1024), weights_blob=blob, pre_nms_cap=cap) as e:
+        raw = _assert_post_exact(e, head, pre_nms_cap=cap)
+        assert raw["n_candidates"] > capi.CAND_CAP and raw["num_dets"] > 0
+
+
 # ---------------------------------------------------------------- end to end / API
 def test_detect_api_end_to_end(eng, onet, frame0):
     """detect() as the reference tests use it (test/yolo_test.cpp:27-36)."""
@@ -211,14 +238,39 @@ def test_detect_api_end_to_end(eng, onet, frame0):
     ref = oracle.decode_nms(onet.forward(oracle.preprocess(frame0, 640)), 640, 14, 8)
     got = {(int(a), int(c)): i for i, (a, c) in enumerate(zip(raw["anchors"], raw["classes"]))}
     want = {(int(a), int(c)): i for i, (a, c) in enumerate(zip(ref["anchors"], ref["classes"]))}
+    # frame0 at the default thresholds is NOT a margin fixture (max_det binds, candidates sit on both thresholds):
+    # here only the shared survivors are compared; set identity is asserted in test_margin_fixtures_*
     common = set(got) & set(want)
     assert len(common) >= 0.9 * max(len(want), 1)
     for k in common:
-        stride = 8 if k[0] < 6400 else (16 if k[0] < 8000 else 32)
-        # a logit error e moves a DFL side by <~ e bins = e * stride px: 6e-2 bins
-        assert np.abs(raw["boxes"][got[k]] - ref["boxes"][want[k]]).max() <= 0.06 * stride
-        assert abs(raw["scores"][got[k]] - ref["scores"][want[k]]) <= 5e-3
-        assert np.abs(raw["kpts"][got[k]] - ref["kpts"][want[k]]).max() <= 0.12 * stride
+        assert np.abs(raw["boxes"][got[k]] - ref["boxes"][want[k]]).max() <= BOX_TOL(_stride(k[0]))
+        assert abs(raw["scores"][got[k]] - ref["scores"][want[k]]) <= SCORE_TOL
+        assert np.abs(raw["kpts"][got[k]] - ref["kpts"][want[k]]).max() <= KPT_TOL
+
+
+def test_margin_fixtures_survivor_set_identical_end_to_end(blob):
+    """on frames whose every decode / NMS decision is clear of fp16 noise (tests/golden/make_margin.py) the
+    HIP path, frame in -> detections out, returns EXACTLY the fp32 oracle's survivors, in the oracle's order."""
+    m = json.load(open(golden_path("margin_cases.json")))
+    assert len(m["cases"]) >= 4
+    worst = {8: [0.0, 0.0], 16: [0.0, 0.0], 32: [0.0, 0.0]}
+    for c in m["cases"]:
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, score_thr=c["score_thr"], iou_thr=c["iou_thr"],
+                        max_det=m["max_det"], pre_nms_cap=m["pre_nms_cap"]) as e:
+            _load(e, 0, frames.synthetic_frame(c["frame"]))
+            e.detect(0)
+            raw = e.read_raw(0)
+        assert raw["n_candidates"] == c["n_candidates"], c["frame"]
+        assert list(zip(raw["anchors"].tolist(), raw["classes"].tolist())) == list(zip(c["anchors"], c["classes"])), c["frame"]
+        for i, a in enumerate(c["anchors"]):
+            db = float(np.abs(raw["boxes"][i] - np.array(c["boxes"][i], np.float32)).max())
+            dk = float(np.abs(raw["kpts"][i] - np.array(c["kpts"][i], np.float32)).max())
+            w = worst[_stride(a)]
+            w[0], w[1] = max(w[0], db), max(w[1], dk)
+            assert db <= BOX_TOL(_stride(a)), (c["frame"], a, db)
+            assert dk <= KPT_TOL, (c["frame"], a, dk)
+            assert abs(float(raw["scores"][i]) - c["scores"][i]) <= SCORE_TOL
+    print("margin fixtures: max |d box|, |d kpt| px per stride:", worst)
 
 
 def test_fused_pnp_matches_oracle(eng, frame0):
@@ -339,6 +391,102 @@ def test_tile_choice_is_bitwise_neutral(blob, frame0):
                 e.detect(0)                       # single-frame step on the batched engine: its own tile set
                 heads.append(e.read_head(0).copy())
     assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2])
+
+
+def _bench_tune_cache(tmp_path, monkeypatch):
+    """Seed the autotuner exactly as bench.py does (its own copy of profiles/*_tune_cache.txt)."""
+    import os, shutil
+    from conftest import ROOT
+    import bench
+    seed = bench.tune_cache_seed()
+    mine = tmp_path / "tune.txt"
+    shutil.copyfile(seed, mine)
+    monkeypatch.setenv("IRMV_TUNE_CACHE", str(mine))
+    monkeypatch.setenv("IRMV_TUNE_WARN", "1")
+
+
+def test_benchmarked_configuration_is_bitwise_the_single_slot_engine(blob, onet, tmp_path, monkeypatch):
+    """bench.py's configuration -- 128 slots replayed as two concurrent 64-frame hipGraphs with the tiles of the
+    committed tune cache (images-per-workgroup pipelines, 64-frame grids of the front / C2f / SPPF / decode kernels) --
+    under assertions: every slot's head and detections bitwise equal a 1-slot engine's detect() on the same frame, and
+    first / middle / last slots within tolerance of the fp32 oracle."""
+    B = 128
+    imgs = [frames.synthetic_frame(200 + i) for i in range(B)]
+    _bench_tune_cache(tmp_path, monkeypatch)
+    with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=B) as e:
+        assert e.num_streams == 2
+        names = [st["name"] for st in e.profile(0, B // 2)]
+        assert any("_i4" in n or "_i2" in n for n in names), names       # several images per workgroup are in play
+        for s in range(B):
+            _load(e, s, imgs[s])
+        e.submit(0, B, h2d=True)
+        e.wait()
+        heads = [e.read_head(s).copy() for s in range(B)]
+        raws = [e.read_raw(s) for s in range(B)]
+        # second replay from HBM-resident frames, as the timed loop does
+        e.submit(0, B, h2d=False)
+        e.wait()
+        for s in (0, 63, 64, 127):
+            assert np.array_equal(e.read_head(s), heads[s])
+    monkeypatch.delenv("IRMV_TUNE_CACHE")
+    with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=1) as one:
+        for s in range(B):
+            _load(one, 0, imgs[s])
+            one.detect(0)
+            assert np.array_equal(one.read_head(0), heads[s]), s
+            r = one.read_raw(0)
+            assert r["num_dets"] == raws[s]["num_dets"] and np.array_equal(r["anchors"], raws[s]["anchors"]), s
+            assert np.array_equal(r["boxes"], raws[s]["boxes"]) and np.array_equal(r["scores"], raws[s]["scores"]), s
+            assert np.array_equal(r["kpts"], raws[s]["kpts"]), s
+    assert not np.array_equal(heads[0], heads[1])
+    for s in (0, 63, 64, 127):
+        ho = onet.forward(oracle.preprocess(imgs[s], 640))
+        assert np.abs(heads[s] - ho).max() <= HEAD_TOL, s
+        exp = oracle.decode_nms(heads[s], 640, 14, 8)
+        assert raws[s]["num_dets"] == exp["num_dets"] and np.array_equal(raws[s]["anchors"], exp["anchors"])
+        assert np.array_equal(raws[s]["boxes"], exp["boxes"])
+
+
+def test_two_engines_with_independent_lifetimes(blob, frame0):
+    """The reference node owns three engines (src/irm_detector.cpp:35-38): create A, create and destroy B, then A must
+    still replay its graphs (upload included) and give the same bits."""
+    a = YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=4)
+    for s in range(4):
+        _load(a, s, frames.synthetic_frame(s))
+    a.submit(0, 4); a.wait()
+    h0 = a.read_head(3).copy()
+    b = YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=1)
+    _load(b, 0, frame0)
+    b.detect()
+    b.close()
+    a.submit(0, 4, h2d=True); a.wait()
+    assert np.array_equal(a.read_head(3), h0)
+    a.submit(0, 4, h2d=False); a.wait()
+    assert np.array_equal(a.read_head(3), h0)
+    a.close()
+
+
+def test_pipelined_slots_overlap_and_match_detect(blob):
+    """a13: slot n+1 is submitted (upload on the copy stream) while slot n is in flight; wait_slots() takes each result
+    as it completes.  Same bits as synchronous detect()."""
+    imgs = [frames.synthetic_frame(300 + i) for i in range(6)]
+    with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3) as e:
+        want = []
+        for im in imgs:
+            _load(e, 0, im)
+            e.detect(0)
+            want.append(e.read_raw(0))
+        got = []
+        _load(e, 0, imgs[0]); e.submit(0, 1)
+        for i in range(6):
+            if i + 1 < 6:
+                _load(e, (i + 1) % 3, imgs[i + 1])
+                e.submit((i + 1) % 3, 1)               # in flight together with slot i % 3
+            e.wait_slots(i % 3, 1)
+            got.append(e.read_raw(i % 3))
+        e.wait()
+    for w, g in zip(want, got):
+        assert w["num_dets"] == g["num_dets"] and np.array_equal(w["boxes"], g["boxes"]) and np.array_equal(w["scores"], g["scores"])
 
 
 @pytest.mark.parametrize("size,net,mode,rot,swap,fused", [

@@ -136,3 +136,20 @@ def test_parse_output_scaling():
     assert np.array_equal(out, b * np.array([2.0, 1.6, 2.0, 1.6], np.float32))
     lb = oracle.parse_output(b, 1280, 1024, 640, 1)       # letterbox: r = 0.5, pad_y = 64
     assert np.allclose(lb, (b - np.array([0, 64, 0, 64], np.float32)) * 2.0)
+
+
+def test_margin_fixtures_hold_under_fp16_noise(blob, onet):
+    """tests/golden/margin_cases.json (made by make_margin.py from the fp32 oracle): the fp32 oracle reproduces the
+    committed survivors, and the fp16-EMULATING oracle -- a differently rounded head -- returns the identical
+    survivor set, i.e. the margins do what they are built for."""
+    from irmv_detection_amd import frames
+    m = json.load(open(golden_path("margin_cases.json")))
+    assert len(m["cases"]) >= 4
+    for c in m["cases"][:3]:
+        x = oracle.preprocess(frames.synthetic_frame(c["frame"]), 640)
+        for emu in (False, True):
+            d = oracle.decode_nms(onet.forward(x, emulate_fp16=emu), 640, 14, 8, c["score_thr"], c["iou_thr"], m["max_det"], m["pre_nms_cap"])
+            assert d["n_candidates"] == c["n_candidates"]
+            assert d["anchors"].tolist() == c["anchors"] and d["classes"].tolist() == c["classes"], (c["frame"], emu)
+            assert 0 < d["num_dets"] < d["n_candidates"]                  # something is suppressed: not vacuous
+        assert np.array_equal(d["anchors"], np.array(c["anchors"]))
