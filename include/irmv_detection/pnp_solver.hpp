@@ -6,6 +6,7 @@
 
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -19,13 +20,18 @@ namespace irmv_detection
 class PnPSolver
 {
 public:
-  PnPSolver(const std::array<double, 9> & camera_matrix, const std::vector<double> & distortion_coefficients)
+  // The reference's constructor (pnp_solver.hpp:15-17); `device`: HIP ordinal, -1 = IRMV_DEVICE or 0
+  PnPSolver(const std::array<double, 9> & camera_matrix, const std::vector<double> & distortion_coefficients, int device = -1)
   {
+    if (device < 0) {
+      const char * v = std::getenv("IRMV_DEVICE");
+      device = v ? std::atoi(v) : 0;
+    }
     double d[5] = {0, 0, 0, 0, 0};
     for (size_t i = 0; i < 5 && i < distortion_coefficients.size(); i++) d[i] = distortion_coefficients[i];
     cx_ = camera_matrix[2];
     cy_ = camera_matrix[5];
-    if (irmv_pnp_create(0, camera_matrix.data(), d, &pnp_) != IRMV_OK)
+    if (irmv_pnp_create(device, camera_matrix.data(), d, &pnp_) != IRMV_OK)
       throw std::runtime_error(std::string("PnPSolver: ") + irmv_last_error());
   }
   ~PnPSolver() { irmv_pnp_destroy(pnp_); }

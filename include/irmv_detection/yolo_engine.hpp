@@ -42,11 +42,22 @@ public:
     bool operator==(const bbox & o) const { return xyxy == o.xyxy && score == o.score && class_id == o.class_id; }
   };
 
-  YoloEngine(const std::string & onnx_file_path, cv::Size src_image_size, bool enable_profiling = false)
+  // HIP device used when none is given: IRMV_DEVICE (one process or thread per GPU sets it), else 0
+  static int default_device()
+  {
+    const char * v = std::getenv("IRMV_DEVICE");
+    return v ? std::atoi(v) : 0;
+  }
+
+  // The reference's constructor (yolo_engine.hpp:28-30).  Extension arguments: `device` (HIP ordinal, -1 = default_device())
+  // and `warm_up_now` (false: the owner calls warm_up() itself, e.g. after building several engines).
+  YoloEngine(const std::string & onnx_file_path, cv::Size src_image_size, bool enable_profiling = false, int device = -1,
+             bool warm_up_now = true)
   : src_image_size_(src_image_size), enable_profiling_(enable_profiling)
   {
     irmv_engine_cfg cfg;
     irmv_engine_cfg_default(&cfg);
+    cfg.device = device >= 0 ? device : default_device();
     cfg.src_width = src_image_size.width;
     cfg.src_height = src_image_size.height;
     cfg.num_slots = 1;  // one engine per TripleBuffer slot, like the reference node
@@ -60,7 +71,25 @@ public:
     src_image_buffer_ = irmv_engine_src_buffer(engine_, 0);
     rotated_ = cv::Mat(src_image_size.height, src_image_size.width, CV_8UC3);
     dets_.resize(static_cast<size_t>(irmv_engine_max_det(engine_)));
-    for (int i = 0; i < 50; i++) detect();  // warm-up, as src/yolo_engine.cpp:114-116
+    if (warm_up_now) warm_up();
+  }
+
+  void warm_up()
+  {
+    for (int i = 0; i < 50; i++) detect();  // as src/yolo_engine.cpp:114-116
+  }
+
+  // true: the model has a keypoint head and every detection carries its four armor points and pose (irmv_det);
+  // false: a bbox-only model like the reference's -- the points come from extract_armors()
+  bool has_keypoint_head() const { return irmv_engine_point_source(engine_) == IRMV_POINTS_KEYPOINT_HEAD; }
+
+  // The node's live parameters of the classical extraction (src/irm_detector.cpp:372-403)
+  void set_extract_params(int binary_threshold, float light_min_ratio, float light_max_ratio, float light_max_angle, double min_small_cd,
+                          double max_small_cd, double min_large_cd, double max_large_cd)
+  {
+    const double cd[4] = {min_small_cd, max_small_cd, min_large_cd, max_large_cd};
+    if (irmv_engine_set_extract_params(engine_, binary_threshold, light_min_ratio, light_max_ratio, light_max_angle, cd) != IRMV_OK)
+      throw std::runtime_error(std::string("YoloEngine::set_extract_params: ") + irmv_last_error());
   }
 
   ~YoloEngine() { irmv_engine_destroy(engine_); }
@@ -71,7 +100,7 @@ public:
   {
     int n = 0;
     const int rc = irmv_engine_detect(engine_, 0, dets_.data(), static_cast<int>(dets_.size()), &n);
-    if (rc != IRMV_OK && rc != IRMV_ERR_OVERFLOW) throw std::runtime_error(std::string("YoloEngine::detect: ") + irmv_last_error());
+    if (rc != IRMV_OK) throw std::runtime_error(std::string("YoloEngine::detect: ") + irmv_last_error());
     rotated_valid_ = false;
     std::vector<bbox> out;
     out.reserve(static_cast<size_t>(n));

@@ -156,17 +156,17 @@ uint8_t *irmv_engine_src_buffer(irmv_engine *e, int slot);
  * frame in HBM, and for HBM-resident benchmarking). */
 void *irmv_engine_src_device_buffer(irmv_engine *e, int slot);
 
-#define IRMV_SUBMIT_H2D 1u    /* copy pinned slots -> HBM first (async, on the engine's upload stream) */
-#define IRMV_SUBMIT_INLINE 2u /* upload, kernels and download on ONE stream (no cross-stream events): lowest latency for a
-                                 synchronous single-slot call, no copy/compute overlap */
+#define IRMV_SUBMIT_H2D 1u          /* copy the pinned slots -> HBM first */
+#define IRMV_SUBMIT_ASYNC_UPLOAD 2u /* ... on the engine's upload stream, event-chained to the compute stream: this
+                                       group's frames cross PCIe while other groups' kernels run (one cross-stream hop) */
 
 /* Enqueue one step for slots [first, first+count) and return immediately:
- *   upload stream   : async H2D of the frames (IRMV_SUBMIT_H2D)
- *   compute stream  : ONE hipGraph {preprocess -> network -> decode -> NMS -> keypoints -> PnP}
- *   download stream : async D2H of the results
- * chained by events, so the upload of one slot group overlaps the kernels of another -- the dGPU form of the
- * reference's TripleBuffer hand-off (triple_buffer.hpp:24-40, src/camera.cpp:40-61).  count == 1 is the reference's
- * per-slot detect(); count > 1 batches independent frames through every kernel.  One thread submits. */
+ *   [async H2D of the frames] -> ONE hipGraph {preprocess -> network -> decode -> NMS -> keypoints -> PnP} ->
+ *   async D2H of the results.
+ * With IRMV_SUBMIT_ASYNC_UPLOAD the upload rides a side stream -- the dGPU form of the reference's TripleBuffer
+ * hand-off (triple_buffer.hpp:24-40, src/camera.cpp:40-61): submit slot n+1 while slot n is in flight, collect each
+ * with irmv_engine_wait_slots().  count == 1 is the reference's per-slot detect(); count > 1 batches independent
+ * frames through every kernel.  One thread submits. */
 int irmv_engine_submit(irmv_engine *e, int first_slot, int count, uint32_t flags);
 /* Block until everything submitted so far is done and host-visible. */
 int irmv_engine_wait(irmv_engine *e);
@@ -187,6 +187,13 @@ int irmv_engine_rotated_image(irmv_engine *e, int slot, uint8_t *dst_hwc);
  * for each of the n boxes (xyxy, rotated-frame pixels) on the slot's current frame -> out[i].kpts (LB, LT, RT,
  * RB), armor_valid, armor_size, n_lights, and the PnP pose.  Works for any model / point_source. */
 int irmv_engine_extract_armors(irmv_engine *e, int slot, const float *xyxy, int n, irmv_det *out);
+/* The node's live parameters of that extraction (IrmDetector::param_event_callback, src/irm_detector.cpp:372-403):
+ * binary_threshold, light.{min_ratio,max_ratio,max_angle}, armor.{min_small,max_small,min_large,max_large}_center_distance.
+ * Takes effect from the next submit / extract call. */
+int irmv_engine_set_extract_params(irmv_engine *e, int binary_threshold, float light_min_ratio, float light_max_ratio,
+                                   float light_max_angle, const double center_distances[4]);
+/* IRMV_POINTS_KEYPOINT_HEAD or IRMV_POINTS_CLASSICAL: where this engine's four armor points come from (AUTO resolved). */
+int irmv_engine_point_source(const irmv_engine *e);
 
 /* ---- stage-wise read-backs used by the parity tests -------------------- */
 int irmv_engine_read_input(irmv_engine *e, int slot, float *chw);             /* [3][net][net], as the reference's input_buffer_ */

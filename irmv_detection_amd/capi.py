@@ -14,7 +14,7 @@ OK, ERR_ARG, ERR_HIP, ERR_MODEL, ERR_OVERFLOW = 0, -1, -2, -3, -4
 RESIZE_STRETCH, RESIZE_LETTERBOX = 0, 1
 ARMOR_SMALL, ARMOR_LARGE = 0, 1
 SUBMIT_H2D = 1
-SUBMIT_INLINE = 2
+SUBMIT_ASYNC_UPLOAD = 2
 POINTS_AUTO, POINTS_KEYPOINT_HEAD, POINTS_CLASSICAL = 0, 1, 2
 NUM_CLASSES = 14
 MAX_DET_CAP = 256
@@ -85,6 +85,8 @@ SYMBOLS = [
     ("irmv_engine_submit", C.c_int, [_P, C.c_int, C.c_int, C.c_uint32]),
     ("irmv_engine_wait", C.c_int, [_P]),
     ("irmv_engine_wait_slots", C.c_int, [_P, C.c_int, C.c_int]),
+    ("irmv_engine_set_extract_params", C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_double)]),
+    ("irmv_engine_point_source", C.c_int, [_P]),
     ("irmv_engine_results", C.c_int, [_P, C.c_int, C.POINTER(Det), C.c_int, C.POINTER(C.c_int)]),
     ("irmv_engine_detect", C.c_int, [_P, C.c_int, C.POINTER(Det), C.c_int, C.POINTER(C.c_int)]),
     ("irmv_engine_last_detect_ms", C.c_double, [_P]),

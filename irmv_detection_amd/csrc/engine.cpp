@@ -137,8 +137,8 @@ struct GraphKey {
     }
 };
 
-// Events of one submitted slot group [first, first + count): upload done -> compute may start; compute done ->
-// download may start and the device frames may be overwritten; download done -> results are host-visible.
+// Events of one submitted slot group [first, first + count): h2d = its frames are in HBM (async upload only);
+// out = its kernels have run and its results are host-visible (so its device frames may be overwritten too).
 struct SlotGroup {
     int first = 0, count = 0;
     hipEvent_t h2d = nullptr, done = nullptr, out = nullptr;
@@ -157,9 +157,9 @@ struct irmv_engine {
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // Detect-branch lanes (only ever used under stream capture)
     hipEvent_t ev_level[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
     bool fork_head = false;   // opt-in (IRMV_FORK_HEAD=1): measured 11 % SLOWER than the linear graph at 16 frames/step
-    // frame hand-off: uploads and downloads ride streams of their own, chained to the compute
-    // streams by one event triple per submitted slot group
-    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    // frame hand-off: uploads can ride a stream of their own, chained to the compute streams by the
+    // events of the submitted slot group
+    hipStream_t h2d_stream = nullptr;
     std::map<std::pair<int, int>, SlotGroup> groups;   // (first, count) -> events of that group's last submit
     std::vector<SlotGroup *> slot_owner;               // per slot: the group whose submit touched it last
     bool inline_copies = false;                        // IRMV_INLINE_COPIES=1: round-1 behaviour, copies on the compute stream
@@ -223,7 +223,6 @@ irmv_engine::~irmv_engine()
     for (int i = 0; i < 3; i++)
         if (side[i]) (void)hipStreamSynchronize(side[i]);
     if (h2d_stream) (void)hipStreamSynchronize(h2d_stream);
-    if (d2h_stream) (void)hipStreamSynchronize(d2h_stream);
     if (dbg_dev) {   // diagnostic: phase cycles of the last nms_pnp launch per slot (100 MHz s_memtime-independent clock64)
         std::vector<long long> h((size_t)cfg.num_slots * 8);
         if (hipMemcpy(h.data(), dbg_dev, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -253,7 +252,6 @@ irmv_engine::~irmv_engine()
     for (int i = 0; i < 7; i++)
         if (extra_streams[i]) (void)hipStreamDestroy(extra_streams[i]);
     if (h2d_stream) (void)hipStreamDestroy(h2d_stream);
-    if (d2h_stream) (void)hipStreamDestroy(d2h_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -499,7 +497,6 @@ static int build_engine(irmv_engine *e)
     e->num_streams = std::max(1, std::min({e->num_streams, 8, c.num_slots}));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->h2d_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&e->d2h_stream, hipStreamNonBlocking));
     { const char *ic = getenv("IRMV_INLINE_COPIES"); e->inline_copies = ic && ic[0] == '1'; }
     e->slot_owner.assign(S, nullptr);
     e->frame_bytes = (size_t)c.src_width * c.src_height * 3;
@@ -1164,8 +1161,13 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     const int net = e->cfg.net_size;
     const bool capturing = (flags & 0x40000000u) != 0;
     const bool materialize = (flags & 0x20000000u) != 0;
-    HIP_TRY(hipMemsetAsync(e->counts + (size_t)first * kCountStride, 0, (size_t)count * kCountStride * 4, e->stream));
-    const PostArgs pa = post_args(e, first);
+    // The per-frame candidate counters are reset by nms_pnp_kernel itself once it has read them (they start at zero),
+    // so a step carries no memset node.  IRMV_COUNTS_MEMSET=1 restores the round-1 scheme (memset node at the head of
+    // the step, no self-reset) for the diagnosis recorded in DESIGN.md section 9.
+    static const bool counts_memset = [] { const char *v = getenv("IRMV_COUNTS_MEMSET"); return v && v[0] == '1'; }();
+    if (counts_memset) HIP_TRY(hipMemsetAsync(e->counts + (size_t)first * kCountStride, 0, (size_t)count * kCountStride * 4, e->stream));
+    PostArgs pa = post_args(e, first);
+    pa.self_reset = counts_memset ? 0 : 1;
     // Under capture the three Detect branches ride side streams: branch chains of level i depend only on
     // P(i), so the big P3 head convs overlap the small neck / P4 / P5 layers in the replayed graph.
     const bool fork = capturing && e->fork_head && !post_only;
@@ -1336,50 +1338,49 @@ static int group_of(irmv_engine *e, int first, int count, SlotGroup **out)
     return IRMV_OK;
 }
 
-// One slot group through the hand-off pipeline (the dGPU form of the reference's TripleBuffer,
-// include/irmv_detection/triple_buffer.hpp:24-40, whose slots ARE the engines' input memory):
+// One slot group: [upload] -> ONE hipGraph -> download of the results, in order on compute stream `st`.
 //
-//   upload stream    [wait: previous step of this group has read its device frames]  H2D frames   -> ev h2d
-//   compute stream   [wait: ev h2d; previous results of this group have left HBM]     hipGraph     -> ev done
-//   download stream  [wait: ev done]                                                  D2H results  -> ev out
+// IRMV_SUBMIT_ASYNC_UPLOAD moves the upload to the engine's upload stream (the dGPU form of the
+// reference's TripleBuffer, include/irmv_detection/triple_buffer.hpp:24-40, whose slots ARE the engines' input memory):
 //
-// The three streams only meet at these events, so group B's upload runs under group A's kernels and A's
-// download under B's kernels: with two or more groups in flight the PCIe link and the CUs are busy at once.
+//   upload stream    [wait: this group's previous step is done with its device frames]  H2D frames  -> ev h2d
+//   compute stream   [wait: ev h2d]  hipGraph, D2H results                                           -> ev out
+//
+// so group B's frames cross PCIe while group A's kernels run.  The price is one cross-stream event hop per group
+// (measured on this stack: scripts/probes/stream_probe.cpp), which is why a lone synchronous detect() -- nothing to
+// overlap with -- keeps everything on one stream, and why the (tiny) download never leaves the compute stream.
 static int submit_group(irmv_engine *e, int f, int c, uint32_t flags, hipStream_t st)
 {
     hipGraphExec_t ge;
     TRY(get_graph(e, f, c, 0, false, &ge));
     SlotGroup *g;
     TRY(group_of(e, f, c, &g));
-    const bool inl = e->inline_copies || (flags & IRMV_SUBMIT_INLINE);
-    hipStream_t up = inl ? st : e->h2d_stream, down = inl ? st : e->d2h_stream;
-    // slots last used through a different grouping: order behind that group's download
+    const bool async_up = (flags & IRMV_SUBMIT_H2D) && (flags & IRMV_SUBMIT_ASYNC_UPLOAD) && !e->inline_copies;
+    hipStream_t up = async_up ? e->h2d_stream : st;
+    // slots last used through a different grouping: order behind that group's completion
     SlotGroup *seen[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int s = f; s < f + c; s++) {
         SlotGroup *o = e->slot_owner[s];
         e->slot_owner[s] = g;
         if (!o || o == g || !o->in_flight || o == seen[0] || o == seen[1] || o == seen[2] || o == seen[3]) continue;
         seen[3] = seen[2]; seen[2] = seen[1]; seen[1] = seen[0]; seen[0] = o;
-        HIP_TRY(hipStreamWaitEvent(up, o->out, 0));
-        if (st != up) HIP_TRY(hipStreamWaitEvent(st, o->out, 0));
+        if (o->compute != st) HIP_TRY(hipStreamWaitEvent(st, o->out, 0));
+        if (up != st) HIP_TRY(hipStreamWaitEvent(up, o->out, 0));
     }
+    if (g->in_flight && g->compute != st) HIP_TRY(hipStreamWaitEvent(st, g->out, 0));   // the group moved to another compute stream
     if (flags & IRMV_SUBMIT_H2D) {
-        if (g->in_flight && up != g->compute) HIP_TRY(hipStreamWaitEvent(up, g->done, 0));
-        TRY(copy_in(e, f, c, up));
-        if (up != st) {
+        if (async_up) {
+            if (g->in_flight) HIP_TRY(hipStreamWaitEvent(up, g->out, 0));   // previous step has consumed the device frames
+            TRY(copy_in(e, f, c, up));
             HIP_TRY(hipEventRecord(g->h2d, up));
             HIP_TRY(hipStreamWaitEvent(st, g->h2d, 0));
+        } else {
+            TRY(copy_in(e, f, c, st));
         }
     }
-    if (g->in_flight && (down != st || g->compute != st)) HIP_TRY(hipStreamWaitEvent(st, g->out, 0));
     HIP_TRY(hipGraphLaunch(ge, st));
-    if (down != st) {
-        HIP_TRY(hipEventRecord(g->done, st));
-        HIP_TRY(hipStreamWaitEvent(down, g->done, 0));
-    }
-    TRY(copy_out(e, f, c, down));
-    HIP_TRY(hipEventRecord(g->out, down));
-    if (down == st) HIP_TRY(hipEventRecord(g->done, st));
+    TRY(copy_out(e, f, c, st));
+    HIP_TRY(hipEventRecord(g->out, st));
     g->in_flight = true;
     g->compute = st;
     return IRMV_OK;
@@ -1424,7 +1425,6 @@ extern "C" int irmv_engine_wait(irmv_engine *e)
     HIP_TRY(hipStreamSynchronize(e->h2d_stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamSynchronize(e->extra_streams[i - 1]));
-    HIP_TRY(hipStreamSynchronize(e->d2h_stream));
     for (auto &kv : e->groups) kv.second.in_flight = false;
     return IRMV_OK;
 }
@@ -1478,10 +1478,8 @@ extern "C" int irmv_engine_results(irmv_engine *e, int slot, irmv_det *out, int 
 extern "C" int irmv_engine_detect(irmv_engine *e, int slot, irmv_det *out, int cap, int *n)
 {
     const auto t0 = std::chrono::high_resolution_clock::now();
-    static const bool inline_detect = [] { const char *v = getenv("IRMV_DETECT_STREAMED"); return !(v && v[0] == '1'); }();
-    // a synchronous single-slot call has nothing to overlap with: upload, graph and download ride ONE stream (no
-    // cross-stream event hops on the latency path).  IRMV_DETECT_STREAMED=1 sends it through the three-stream pipeline.
-    TRY(irmv_engine_submit(e, slot, 1, IRMV_SUBMIT_H2D | (inline_detect ? IRMV_SUBMIT_INLINE : 0u)));
+    // a synchronous single-slot call has nothing to overlap with: upload, graph and download ride ONE stream
+    TRY(irmv_engine_submit(e, slot, 1, IRMV_SUBMIT_H2D));
     TRY(irmv_engine_wait_slots(e, slot, 1));
     const int rc = irmv_engine_results(e, slot, out, cap, n);
     e->last_detect_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -1540,6 +1538,37 @@ extern "C" int irmv_engine_extract_armors(irmv_engine *e, int slot, const float 
         o.armor_valid = d.armor_valid;
         o.armor_size = d.armor_size;
         o.n_lights = d.n_lights;
+    }
+    return IRMV_OK;
+}
+
+extern "C" int irmv_engine_point_source(const irmv_engine *e)
+{
+    if (!e) return -1;
+    return e->classical ? IRMV_POINTS_CLASSICAL : IRMV_POINTS_KEYPOINT_HEAD;
+}
+
+extern "C" int irmv_engine_set_extract_params(irmv_engine *e, int binary_threshold, float light_min_ratio, float light_max_ratio,
+                                              float light_max_angle, const double cd[4])
+{
+    if (!e || !cd) return fail(IRMV_ERR_ARG, "null argument");
+    if (binary_threshold < 0 || binary_threshold > 255) return fail(IRMV_ERR_ARG, "binary_threshold must be 0..255");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    TRY(irmv_engine_wait(e));
+    irmv_engine_cfg &c = e->cfg;
+    const bool same = c.binary_threshold == binary_threshold && c.light_min_ratio == light_min_ratio && c.light_max_ratio == light_max_ratio &&
+                      c.light_max_angle == light_max_angle && c.armor_min_small_center_distance == cd[0] &&
+                      c.armor_max_small_center_distance == cd[1] && c.armor_min_large_center_distance == cd[2] &&
+                      c.armor_max_large_center_distance == cd[3];
+    if (same) return IRMV_OK;
+    c.binary_threshold = binary_threshold;
+    c.light_min_ratio = light_min_ratio; c.light_max_ratio = light_max_ratio; c.light_max_angle = light_max_angle;
+    c.armor_min_small_center_distance = cd[0]; c.armor_max_small_center_distance = cd[1];
+    c.armor_min_large_center_distance = cd[2]; c.armor_max_large_center_distance = cd[3];
+    // captured steps of the classical mode carry these values as kernel arguments: re-capture on next use
+    if (e->classical) {
+        for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.second);
+        e->graphs.clear();
     }
     return IRMV_OK;
 }

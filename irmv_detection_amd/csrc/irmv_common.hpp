@@ -161,6 +161,7 @@ struct PostArgs {
     int armor_size;
     const PnpConst *pnp;      // device copy (keeps the kernel-argument struct out of scratch)
     long long *dbg;           // optional [B][8] phase stamps of nms_pnp_kernel (diagnostic builds of the engine only)
+    int self_reset;           // 1: nms_pnp_kernel zeroes its frame's candidate counter after reading it
 };
 void launch_decode(const PostArgs &a, int batch, hipStream_t s);
 void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s);

@@ -245,7 +245,10 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define IRMV_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[b * 8 + (k)] = clock64(); } while (0)
     IRMV_STAMP(0);
-    const int n_total = a.counts[b * kCountStride];
+    // the list holds at most key_cap = A * nc pairs; a counter beyond that can only be stale state, and the walk below
+    // must never leave this frame's list whatever the counter says
+    const int n_raw = a.counts[b * kCountStride];
+    const int n_total = n_raw < a.key_cap ? n_raw : a.key_cap;
     const unsigned long long *gk = a.keys + (size_t)b * a.key_cap;
     const unsigned long long *sorted;
     if (tid < 16) cls_cnt[tid] = 0;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     if (tid == 0) {
         DevFrameOut fo;
         fo.num_dets = kept;
-        fo.n_candidates = n_total;
+        fo.n_candidates = n_raw;
         fo.overflow = 0;   // (the candidate list is sized for every (anchor, class) pair; kept for ABI stability)
         fo.pad = 0;
         a.fout[b] = fo;
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         a.dets[(size_t)b * a.max_det + j] = d;
     }
     __syncthreads();
+    if (a.self_reset && tid == 0) a.counts[b * kCountStride] = 0;   // every thread has read it (barriers above): ready for the next step
     IRMV_STAMP(4);
     if (a.dbg && tid == 0) { a.dbg[b * 8 + 5] = n_total; a.dbg[b * 8 + 6] = kept; }
 #undef IRMV_STAMP

@@ -231,11 +231,11 @@ class YoloEngine:
                         image[y1c:y2c + 1, x] = color
 
     # ---- batched / asynchronous extension (MI355X-first surface) ------------------
-    def submit(self, first_slot: int = 0, count: Optional[int] = None, h2d: bool = True, inline: bool = False) -> None:
-        """Enqueue slots [first_slot, first_slot + count) and return: upload, kernels and download ride three
-        event-chained streams, so the next group's upload overlaps this group's kernels (`inline`: one stream)."""
+    def submit(self, first_slot: int = 0, count: Optional[int] = None, h2d: bool = True, async_upload: bool = False) -> None:
+        """Enqueue slots [first_slot, first_slot + count) and return.  `async_upload`: the frames' H2D copy rides the
+        engine's upload stream, event-chained to the kernels, so it overlaps other slot groups' compute."""
         count = self.num_slots - first_slot if count is None else count
-        flags = (capi.SUBMIT_H2D if h2d else 0) | (capi.SUBMIT_INLINE if inline else 0)
+        flags = (capi.SUBMIT_H2D if h2d else 0) | (capi.SUBMIT_ASYNC_UPLOAD if (h2d and async_upload) else 0)
         capi.check(self._L.irmv_engine_submit(self._h, first_slot, count, flags))
 
     def wait(self) -> None:

@@ -40,6 +40,16 @@ traffic) cd /tmp; export TMPDIR=/tmp
          IRMV_STREAMS=1 run pmc_w 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
          cd $R
          python3 scripts/collect_traffic.py $O/pmc_f/*/*_counter_collection.csv $O/pmc_w/*/*_counter_collection.csv $O/traffic.json ;;
+probe)   run probe_build 120 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 scripts/probes/stream_probe.cpp -o $O/stream_probe
+         run stream_probe 200 $O/stream_probe ;;
+headerr) run head_error 400 python3 scripts/head_error.py ;;
+lat)     TAG=linear run lat_linear 200 python3 scripts/lat_probe.py
+         TAG=fork_head IRMV_FORK_HEAD=1 run lat_fork 200 python3 scripts/lat_probe.py ;;
+repro_old) # diagnosis only: the round-1 counter scheme (memset node at the head of the step, no self-reset); the kernel's clamp keeps
+         # the walk inside the list, n_candidates reports the raw counter
+         cd /tmp; export TMPDIR=/tmp
+         IRMV_COUNTS_MEMSET=1 IRMV_REPRO_REPORT=1 run repro_old 300 rocprofv3 --kernel-trace --output-format csv -d $O/repro_old -- python3 $R/scripts/repro_two_engines.py
+         cd $R ;;
 repro)   # the round-1 fault sequence, ONCE, under the profiler that exposed it, with every allocation range logged
          cd /tmp; export TMPDIR=/tmp
          IRMV_LOG_ALLOC=1 run repro_prof 300 rocprofv3 --kernel-trace --output-format csv -d $O/repro_prof -- python3 $R/scripts/repro_two_engines.py

@@ -17,12 +17,19 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 BIN = os.path.join(ROOT, "tests", "cpp", "_bin")
 
 
-def _compile(src, out, link_hip):
+ORACLE = os.path.join(ROOT, "oracle")
+
+
+def _compile(src, out, link_hip, link_oracle=False):
     os.makedirs(BIN, exist_ok=True)
     cmd = ["g++", "-std=c++20", "-O2", "-pthread", "-Wall", "-I", INC, os.path.join(CPP, src), "-o", out]
     if link_hip:
         _build.build()
         cmd += ["-L", _build.LIB_DIR, "-lirmv_hip", f"-Wl,-rpath,{_build.LIB_DIR}", "-Wl,-rpath-link,/opt/rocm/lib"]
+    if link_oracle:   # the checker, test binaries only
+        from oracle import oracle
+        oracle.build()
+        cmd += ["-I", ORACLE, "-L", ORACLE, "-l:liboracle.so", f"-Wl,-rpath,{ORACLE}"]
     subprocess.check_call(cmd)
     return out
 
@@ -40,6 +47,8 @@ def test_reference_style_code_compiles_against_the_facade():
     assert os.path.exists(exe)
     exe = _compile("camera_stream_test.cpp", os.path.join(BIN, "camera_stream_test"), True)
     assert os.path.exists(exe)
+    exe = _compile("irm_detector_core_test.cpp", os.path.join(BIN, "irm_detector_core_test"), True, link_oracle=True)
+    assert os.path.exists(exe)
 
 
 @pytest.mark.gpu
@@ -49,7 +58,8 @@ def test_reference_test_flow_on_gpu(tmp_path, blob, frame0):
         exe = _compile("yolo_test.cpp", exe, True)
     (tmp_path / "yolov7.irmw").write_bytes(blob)
     frame0.tofile(tmp_path / "frame.bin")
-    out = subprocess.run([exe, str(tmp_path / "yolov7.onnx"), str(tmp_path / "frame.bin"), "5"], capture_output=True, text=True, timeout=300)
+    # 30 runs x 10 iterations, the reference's own count (test/yolo_test.cpp:76-92)
+    out = subprocess.run([exe, str(tmp_path / "yolov7.onnx"), str(tmp_path / "frame.bin"), "30"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     txt = out.stdout
     from irmv_detection_amd.engine import YoloEngine
@@ -89,3 +99,25 @@ def test_camera_stream_330fps_through_the_triple_buffer(tmp_path, blob):
     assert abs(float(m.group(1)) - 330) < 33 and float(m.group(2)) > 0.9 * float(m.group(1)) and float(m.group(4)) < 10.0
     m = re.search(r"unpaced producer_fps (\S+) consumer_fps (\S+)", out.stdout)
     assert float(m.group(2)) > 330        # un-paced, the consumer keeps up with far more than the camera rate
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["kpt", "classical"])
+def test_irm_detector_core_vs_oracle(tmp_path, blob, rm_test_image, kind):
+    """the ROS-free core of the node (detect -> four points -> PnP -> quaternion -> message fields) against
+    the oracle, for a keypoint-head model and for a bbox-only model (the reference's kind: classical extraction)."""
+    from irmv_detection_amd import frames, weights
+    exe = os.path.join(BIN, "irm_detector_core_test")
+    if not os.path.exists(exe):
+        exe = _compile("irm_detector_core_test.cpp", exe, True, link_oracle=True)
+    (tmp_path / "yolov7.irmw").write_bytes(blob if kind == "kpt" else weights.synthetic_blob(0, nk=0))
+    fr = [frames.synthetic_frame(i) for i in range(4)] + [np.ascontiguousarray(rm_test_image)]
+    np.stack(fr).tofile(tmp_path / "frames.bin")
+    out = subprocess.run([exe, str(tmp_path / "yolov7.onnx"), str(tmp_path / "frames.bin"), str(len(fr)), kind],
+                         capture_output=True, text=True, timeout=600)
+    print(out.stdout[-3000:])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    m = re.search(r"bboxes (\d+) armors (\d+) fails 0", out.stdout)
+    assert m and int(m.group(1)) > 0
+    if kind == "kpt":
+        assert int(m.group(2)) > 0

@@ -477,11 +477,11 @@ def test_pipelined_slots_overlap_and_match_detect(blob):
             e.detect(0)
             want.append(e.read_raw(0))
         got = []
-        _load(e, 0, imgs[0]); e.submit(0, 1)
+        _load(e, 0, imgs[0]); e.submit(0, 1, async_upload=True)
         for i in range(6):
             if i + 1 < 6:
                 _load(e, (i + 1) % 3, imgs[i + 1])
-                e.submit((i + 1) % 3, 1)               # in flight together with slot i % 3
+                e.submit((i + 1) % 3, 1, async_upload=True)   # uploads while slot i % 3 is in flight
             e.wait_slots(i % 3, 1)
             got.append(e.read_raw(i % 3))
         e.wait()
