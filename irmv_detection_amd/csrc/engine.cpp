@@ -103,7 +103,7 @@ struct Tensor {
 
 struct SegRef { int t = -1, coff = 0, C = 0, shift = 0; };
 
-enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_DECODE, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2 };
+enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2, OP_C2F32 };
 
 struct Op {
     OpKind kind;
@@ -123,7 +123,9 @@ struct Op {
     int level = -1;    // Detect level of a head op: it may start as soon as P(level) exists
     int signal = -1;   // >= 0: this op produces P(signal); side lanes wait on its event
     char kname[48] = {0};
-    int sub[4] = {-1, -1, -1, -1};   // OP_C2F2: indices of the four layer ops whose weights it uses
+    int sub[4] = {-1, -1, -1, -1};   // OP_C2F2 / OP_C2F32: indices of the layer ops whose weights it uses
+    int mode = 0;                    // OP_C2F32: 0 whole block, 1 cv1 + first bottleneck, 2 last bottleneck + cv2
+    bool shortcut = false;
     int fuse_next = -1;        // LDS 3x3 conv: index of the 1x1 op computed in its epilogue (Detect-head finals), -1 = none
     bool fused_away = false;   // preprocess / model.0 / model.1 when the fused front kernel runs them (kept for read-backs)
 };
@@ -187,9 +189,9 @@ struct irmv_engine {
     DevDet *light_dets_dev = nullptr, *light_dets_host = nullptr;
     float *boxes = nullptr;
     unsigned long long *keys = nullptr;
-    int *counts = nullptr;
-    DevDet *dets_dev = nullptr, *dets_host = nullptr;
-    DevFrameOut *fout_dev = nullptr, *fout_host = nullptr;
+    DevDet *dets_dev = nullptr, *dets_host = nullptr, *dets_host_dev = nullptr;       // *_host_dev: device view of the pinned buffer
+    DevFrameOut *fout_dev = nullptr, *fout_host = nullptr, *fout_host_dev = nullptr;
+    bool zero_copy_results = false;   // the NMS kernel writes its results straight into pinned host memory (no D2H copy)
     half_t *conv0_w = nullptr;
     float *conv0_b = nullptr;
     PostArgs post{};
@@ -405,6 +407,53 @@ static int add_conv(irmv_engine *e, const std::string &layer, SegRef s0, SegRef 
         if (_rc) return _rc; \
     } while (0)
 
+// A C2f block with a 32-channel hidden width (model.4 / model.15 at a 640 net) runs as fused kernels (k_c2f.hip) when its
+// layers have the shapes those kernels are written for: n = 1 -> one launch, n = 2 -> two.  The layer ops stay in the
+// list as `fused_away` (read-backs of the block's internal tensors run them; they are also the bit-exactness reference).
+static int fuse_c2f32(irmv_engine *e, const std::string &prefix, int n, bool shortcut, int cat, int tmp, int out_t)
+{
+    if (const char *ff = getenv("IRMV_FUSED_C2F")) if (ff[0] == '0') return IRMV_OK;
+    const int last = (int)e->ops.size() - 1, first = last - (2 * n + 1);
+    if (n < 1 || n > 2 || first < 0) return IRMV_OK;
+    const Op &c1 = e->ops[first], &c2 = e->ops[last];
+    bool ok = c1.cfg.ks == 1 && c1.cout == 64 && c1.pair && c1.cin % 32 == 0 && c1.s0.C % 32 == 0 && c1.cfg.act == 1 &&
+              (c1.ksteps == 2 || c1.ksteps == 4 || c1.ksteps == 6) && (n == 1 || shortcut) &&
+              c2.cfg.ks == 1 && c2.cout == 64 && c2.pair && c2.cin == (2 + n) * 32 && c2.ksteps == 2 + n && c2.cfg.act == 1 && !c2.cfg.out_f32;
+    for (int i = first + 1; i < last && ok; i++) {
+        const Op &m = e->ops[i];
+        ok = m.cfg.ks == 3 && m.cfg.stride == 1 && m.cin == 32 && m.cout == 32 && m.pair && m.ksteps == 9 && m.cfg.act == 1 && !m.cfg.cin16;
+    }
+    if (!ok) return IRMV_OK;
+    const int bH = c1.Hin, bW = c1.Win;          // (copies: the pushes below may move e->ops)
+    const double c1_bytes = c1.bytes;
+    auto make = [&](int mode, int i_cv1, int i_m1, int i_m2, int i_cv2, const char *nm) {
+        Op op;
+        op.kind = OP_C2F32;
+        op.mode = mode;
+        op.shortcut = shortcut;
+        op.layer = prefix + (mode == 0 ? " (fused)" : (mode == 1 ? " (cv1+m.0)" : " (m.1+cv2)"));
+        snprintf(op.kname, sizeof op.kname, "%s", nm);
+        op.sub[0] = i_cv1; op.sub[1] = i_m1; op.sub[2] = i_m2; op.sub[3] = i_cv2;
+        op.Hin = bH; op.Win = bW;
+        op.out_t = out_t;
+        op.res_t = cat;                              // the block's concat buffer
+        const double px = (double)bH * bW;
+        for (int k = 0; k < 4; k++)
+            if (op.sub[k] >= 0) { op.flops += e->ops[op.sub[k]].flops; e->ops[op.sub[k]].fused_away = true; }
+        // algorithmic bytes: block input once (mode 0 / 1), concat slices written / read, block output, weights
+        if (mode != 2) op.bytes += c1_bytes - px * 64 * 2.0;                       // cv1's inputs + weights
+        if (mode == 1) op.bytes += px * 96 * 2.0;                                   // y0 | y1 | y2 written
+        if (mode == 2) op.bytes += px * 96 * 2.0;                                   // read back
+        if (mode != 1) op.bytes += px * 64 * 2.0;                                   // block output
+        e->ops.push_back(op);
+    };
+    if (n == 1) make(0, first, first + 1, first + 2, last, "c2f32_ab");
+    else { make(1, first, first + 1, first + 2, -1, "c2f32_a"); make(2, -1, first + 3, first + 4, last, "c2f32_b"); }
+    e->lazy_tensors.insert(e->tensors[cat].name);
+    e->lazy_tensors.insert(e->tensors[tmp].name);
+    return IRMV_OK;
+}
+
 static int add_c2f(irmv_engine *e, const std::string &prefix, SegRef s0, SegRef s1, int H, int W, int c2, int n,
                    bool shortcut, int out_t)
 {
@@ -420,6 +469,7 @@ static int add_c2f(irmv_engine *e, const std::string &prefix, SegRef s0, SegRef 
                      (1 + i) * c));
     }
     TRY(add_conv(e, prefix + ".cv2", SegRef{cat, 0, (2 + n) * c, 0}, SegRef{}, H, W, out_t, 0));
+    TRY(fuse_c2f32(e, prefix, n, shortcut, cat, tmp, out_t));
     return IRMV_OK;
 }
 
@@ -679,23 +729,29 @@ static int build_engine(irmv_engine *e)
     // ---- post-processing buffers ----
     TRY(dev_alloc(e, (void **)&e->boxes, (size_t)S * e->A * 16));
     TRY(dev_alloc(e, (void **)&e->keys, (size_t)S * e->A * e->nc * 8));
-    TRY(dev_alloc(e, (void **)&e->counts, (size_t)S * kCountStride * 4));
-    HIP_TRY(hipMemset(e->counts, 0, (size_t)S * kCountStride * 4));
     TRY(dev_alloc(e, (void **)&e->dets_dev, (size_t)S * c.max_det * sizeof(DevDet)));
     TRY(dev_alloc(e, (void **)&e->fout_dev, (size_t)S * sizeof(DevFrameOut)));
     HIP_TRY(hipMemset(e->dets_dev, 0, (size_t)S * c.max_det * sizeof(DevDet)));
     HIP_TRY(hipMemset(e->fout_dev, 0, (size_t)S * sizeof(DevFrameOut)));
-    HIP_TRY(hipHostMalloc((void **)&e->dets_host, (size_t)S * c.max_det * sizeof(DevDet), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&e->fout_host, (size_t)S * sizeof(DevFrameOut), hipHostMallocDefault));
+    // Result records live in mapped, coherent pinned memory: in keypoint mode the NMS kernel stores them there directly
+    // (~20 KB per frame over PCIe, visible to the host once the stream is synchronised), which removes the D2H copies of
+    // a step -- measured 9.6 us per synchronous call on this stack (scripts/probes/stream_probe.cpp), and copies issued
+    // from the compute streams also halve the upload stream's H2D rate.  The classical mode (light_extract_kernel
+    // reads and rewrites the records on the device) keeps device records + a copy.
+    HIP_TRY(hipHostMalloc((void **)&e->dets_host, (size_t)S * c.max_det * sizeof(DevDet), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostMalloc((void **)&e->fout_host, (size_t)S * sizeof(DevFrameOut), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostGetDevicePointer((void **)&e->dets_host_dev, e->dets_host, 0));
+    HIP_TRY(hipHostGetDevicePointer((void **)&e->fout_host_dev, e->fout_host, 0));
     log_range(e, "pinned dets_host", e->dets_host, (size_t)S * c.max_det * sizeof(DevDet));
     log_range(e, "pinned fout_host", e->fout_host, (size_t)S * sizeof(DevFrameOut));
     memset(e->dets_host, 0, (size_t)S * c.max_det * sizeof(DevDet));
     memset(e->fout_host, 0, (size_t)S * sizeof(DevFrameOut));
-    { Op op; op.kind = OP_DECODE; op.layer = "decode"; snprintf(op.kname, sizeof op.kname, "decode");
-      op.bytes = (double)e->A * (kHeadRec * 4 + 16); e->ops.push_back(op); }
-    { Op op; op.kind = OP_NMS; op.layer = "nms_kpt_pnp"; snprintf(op.kname, sizeof op.kname, "nms_pnp"); e->ops.push_back(op); }
+    // decode + sort + NMS + keypoints + PnP: one kernel, one workgroup per frame (k_post.hip)
+    { Op op; op.kind = OP_NMS; op.layer = "decode_nms_kpt_pnp"; snprintf(op.kname, sizeof op.kname, "nms_pnp");
+      op.bytes = (double)e->A * 64.0; e->ops.push_back(op); }
     if (c.point_source == IRMV_POINTS_KEYPOINT_HEAD && e->nk < 8) return fail(IRMV_ERR_MODEL, "point_source = keypoint head, but the model has none");
     e->classical = c.point_source == IRMV_POINTS_CLASSICAL || (c.point_source == IRMV_POINTS_AUTO && e->nk < 8);
+    { const char *z = getenv("IRMV_ZERO_COPY_RESULTS"); e->zero_copy_results = !e->classical && !(z && z[0] == '0'); }
     if (e->classical) {
         Op op; op.kind = OP_LIGHT; op.layer = "extract_armors"; snprintf(op.kname, sizeof op.kname, "light_extract");
         e->ops.push_back(op);
@@ -1148,9 +1204,8 @@ static PostArgs post_args(const irmv_engine *e, int first)
     p.boxes = e->boxes + (size_t)first * e->A * 4;
     p.keys = e->keys + (size_t)first * e->A * e->nc;
     p.key_cap = e->A * e->nc;
-    p.counts = e->counts + (size_t)first * kCountStride;
-    p.dets = e->dets_dev + (size_t)first * e->cfg.max_det;
-    p.fout = e->fout_dev + first;
+    p.dets = (e->zero_copy_results ? e->dets_host_dev : e->dets_dev) + (size_t)first * e->cfg.max_det;
+    p.fout = (e->zero_copy_results ? e->fout_host_dev : e->fout_dev) + first;
     if (p.dbg) p.dbg += (size_t)first * 8;
     return p;
 }
@@ -1161,20 +1216,14 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     const int net = e->cfg.net_size;
     const bool capturing = (flags & 0x40000000u) != 0;
     const bool materialize = (flags & 0x20000000u) != 0;
-    // The per-frame candidate counters are reset by nms_pnp_kernel itself once it has read them (they start at zero),
-    // so a step carries no memset node.  IRMV_COUNTS_MEMSET=1 restores the round-1 scheme (memset node at the head of
-    // the step, no self-reset) for the diagnosis recorded in DESIGN.md section 9.
-    static const bool counts_memset = [] { const char *v = getenv("IRMV_COUNTS_MEMSET"); return v && v[0] == '1'; }();
-    if (counts_memset) HIP_TRY(hipMemsetAsync(e->counts + (size_t)first * kCountStride, 0, (size_t)count * kCountStride * 4, e->stream));
-    PostArgs pa = post_args(e, first);
-    pa.self_reset = counts_memset ? 0 : 1;
+    const PostArgs pa = post_args(e, first);
     // Under capture the three Detect branches ride side streams: branch chains of level i depend only on
     // P(i), so the big P3 head convs overlap the small neck / P4 / P5 layers in the replayed graph.
     const bool fork = capturing && e->fork_head && !post_only;
     bool lane_used[3] = {false, false, false};
     int lane_level[3] = {-1, -1, -1};
     for (const Op &op : e->ops) {
-        if (post_only && op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) continue;
+        if (post_only && op.kind != OP_NMS && op.kind != OP_LIGHT) continue;
         // a step skips the layers a fused kernel covers; a read-back runs only those (and the unfused form of a conv that
         // normally carries a 1x1 in its epilogue)
         if (materialize ? !(op.fused_away || op.fuse_next >= 0) : op.fused_away) continue;
@@ -1188,7 +1237,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             }
             lane_used[ln] = true;
         }
-        if (fork && op.kind == OP_DECODE) {     // join the lanes before post-processing
+        if (fork && op.kind == OP_NMS) {        // join the lanes before post-processing
             for (int ln = 0; ln < 3; ln++)
                 if (lane_used[ln]) {
                     HIP_TRY(hipEventRecord(e->ev_join[ln], e->side[ln]));
@@ -1202,7 +1251,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             HIP_TRY(hipEventCreate(&r.b));
             HIP_TRY(hipEventRecord(r.a, s));
         }
-        const int reps = (ev && op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) ? (int)(flags & 0xffu) : 1;
+        const int reps = (ev && op.kind != OP_LIGHT) ? (int)(flags & 0xffu) : 1;   // every kernel but the light extraction is idempotent
         for (int rep = 0; rep < (reps > 0 ? reps : 1); rep++)
         switch (op.kind) {
         case OP_PRE: {
@@ -1244,6 +1293,28 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             launch_c2f2(a, count, s);
             break;
         }
+        case OP_C2F32: {
+            C2f32Args a{};
+            const Tensor &ct = e->tensors[op.res_t];
+            const Tensor &ot = e->tensors[op.out_t];
+            if (op.sub[0] >= 0) {
+                ConvArgs ca;
+                fill_conv_args(e, e->ops[op.sub[0]], first, count, ca, false);
+                a.s0 = ca.s0; a.s1 = ca.s1; a.cin1 = ca.Cin;
+                a.w_cv1 = e->ops[op.sub[0]].w_packed; a.b_cv1 = e->ops[op.sub[0]].bias;
+            } else {
+                a.cin1 = 32;
+            }
+            a.cat = static_cast<half_t *>(ct.slot(first)); a.cat_ld = ct.C; a.prev_coff = 64;
+            a.out = static_cast<half_t *>(ot.slot(first)); a.out_ld = ot.C;
+            a.H = op.Hin; a.W = op.Win;
+            a.tiles_x = (op.Win + kC2f32TileW - 1) / kC2f32TileW; a.tiles_y = (op.Hin + kC2f32TileH - 1) / kC2f32TileH;
+            a.w_m1 = e->ops[op.sub[1]].w_packed; a.b_m1 = e->ops[op.sub[1]].bias;
+            a.w_m2 = e->ops[op.sub[2]].w_packed; a.b_m2 = e->ops[op.sub[2]].bias;
+            if (op.sub[3] >= 0) { a.w_cv2 = e->ops[op.sub[3]].w_packed; a.b_cv2 = e->ops[op.sub[3]].bias; }
+            if (!launch_c2f32(op.mode, op.shortcut, a, count, s)) return fail(IRMV_ERR_ARG, "no fused C2f kernel for " + op.layer);
+            break;
+        }
         case OP_CONV0: {
             Conv0Args a;
             a.x = static_cast<const half_t *>(e->tensors[e->tensor_idx.at("input")].slot(first));
@@ -1264,7 +1335,6 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             launch_sppf_pool(static_cast<half_t *>(t.slot(first)), count, t.H, t.W, t.C / 4, s);
             break;
         }
-        case OP_DECODE: launch_decode(pa, count, s); break;
         case OP_NMS: launch_nms_pnp(pa, count, s); break;
         case OP_LIGHT: launch_light_extract(light_args(e, first), e->cfg.max_det, count, s); break;
         }
@@ -1289,6 +1359,7 @@ static int copy_in(irmv_engine *e, int first, int count, hipStream_t st)
 static int copy_out(irmv_engine *e, int first, int count, hipStream_t st = nullptr)
 {
     if (!st) st = e->stream;
+    if (e->zero_copy_results) return IRMV_OK;   // the kernel has already written the pinned records
     HIP_TRY(hipMemcpyAsync(e->dets_host + (size_t)first * e->cfg.max_det, e->dets_dev + (size_t)first * e->cfg.max_det,
                            (size_t)count * e->cfg.max_det * sizeof(DevDet), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(e->fout_host + first, e->fout_dev + first, (size_t)count * sizeof(DevFrameOut),
@@ -1689,8 +1760,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
     if (!n) return fail(IRMV_ERR_ARG, "n is null");
     HIP_TRY(hipSetDevice(e->cfg.device));
     // Eager replay of the step's launches on the engine stream, every kernel bracketed by an event
-    // pair.  Idempotent kernels (everything but decode / NMS, which append to the candidate list) are
-    // launched kRep times inside their bracket: an event pair around ONE launch also times ~4 us of
+    // pair.  The kernels are idempotent and are launched kRep times inside their bracket: an event pair around ONE launch also times ~4 us of
     // command-processor hand-over, which would read as kernel time on these 5-80 us kernels.
     // (Event-record nodes inside a captured graph cannot be read back with hipEventElapsedTime on
     // ROCm 7.2: "invalid resource handle".)
@@ -1706,7 +1776,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
         (void)hipEventDestroy(ev[i].a);
         (void)hipEventDestroy(ev[i].b);
         const Op &op = e->ops[ev[i].op];
-        if (op.kind != OP_DECODE && op.kind != OP_NMS && op.kind != OP_LIGHT) ms /= (float)kProfileRepeat;
+        if (op.kind != OP_LIGHT) ms /= (float)kProfileRepeat;
         if (k < cap && stats) {
             irmv_kernel_stat &st = stats[k];
             memset(&st, 0, sizeof st);

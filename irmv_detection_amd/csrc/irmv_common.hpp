@@ -17,8 +17,6 @@ constexpr int kClsOff = 64;
 constexpr int kKptOff = 80;
 constexpr int kCandCap = 8192; // == IRMV_CAND_CAP
 constexpr int kMaxDetCap = 256;
-constexpr int kCountStride = 32; // ints between per-frame candidate counters: one 128-B line each, so the
-                                 // decode kernel's atomics of different frames do not serialise on one line
 
 // ---- preprocess ------------------------------------------------------------
 // One bilinear tap table entry per destination coordinate (built on the host
@@ -89,6 +87,23 @@ struct ConvSeg {
     int shift;        // 1 = the segment is stored at half resolution (nearest 2x upsample folded in)
 };
 
+// fused C2f blocks with a 32-channel hidden width (k_c2f.hip): mode 0 = whole block (n = 1), 1 = cv1 + first
+// bottleneck, 2 = last bottleneck + cv2 (n = 2)
+constexpr int kC2f32TileH = 8, kC2f32TileW = 16;
+struct C2f32Args {
+    ConvSeg s0, s1;       // block input (modes 0, 1): up to two K segments, s0 optionally at half resolution
+    int cin1;             // s0.C + s1.C
+    half_t *cat;          // the block's concat buffer [B][H][W][cat_ld]: y0 | y1 | y2 [| y3], 32 channels each
+    int cat_ld, prev_coff;   // mode 2: channel offset of the previous bottleneck's output inside cat
+    half_t *out;          // block output [B][H][W][out_ld], 64 channels (modes 0, 2)
+    int out_ld;
+    int H, W, tiles_x, tiles_y;
+    const half_t *w_cv1, *w_m1, *w_m2, *w_cv2;   // direct-family packings
+    const float *b_cv1, *b_m1, *b_m2, *b_cv2;
+};
+size_t c2f32_lds_bytes(int mode);
+bool launch_c2f32(int mode, bool shortcut, const C2f32Args &a, int batch, hipStream_t s);
+
 struct ConvArgs {
     ConvSeg s0, s1;
     int Hin, Win;       // input size at the conv's own resolution
@@ -148,9 +163,9 @@ struct PostArgs {
     const float *head_all;    // one allocation: [level][slot (all num_slots)][H*W][kHeadRec]
     int slots_total, first;   // level block offset = lvl_base * slots_total records; this step starts at slot `first`
     float *boxes;             // [B][A][4]
-    unsigned long long *keys; // [B][key_cap]: every (anchor, class) pair above threshold, unsorted
+    unsigned long long *keys; // [B][key_cap]: every (anchor, class) pair above threshold, unsorted (read back only when a frame
+                              // has more candidates than the LDS list holds)
     int key_cap;              // = A * nc: the list can never overflow
-    int *counts;              // [B][kCountStride]
     DevDet *dets;             // [B][max_det]
     DevFrameOut *fout;        // [B]
     int net, A, nc, nk;
@@ -161,9 +176,7 @@ struct PostArgs {
     int armor_size;
     const PnpConst *pnp;      // device copy (keeps the kernel-argument struct out of scratch)
     long long *dbg;           // optional [B][8] phase stamps of nms_pnp_kernel (diagnostic builds of the engine only)
-    int self_reset;           // 1: nms_pnp_kernel zeroes its frame's candidate counter after reading it
 };
-void launch_decode(const PostArgs &a, int batch, hipStream_t s);
 void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s);
 // ---- classical light extraction (k_light.hip) -------------
 constexpr int kLightLdsPoints = 256;         // contours up to this many points are sorted / hulled in LDS

@@ -203,4 +203,294 @@ void launch_c2f2(const C2fArgs &a, int batch, hipStream_t s)
     hipLaunchKernelGGL(c2f2_kernel, dim3(a.tiles * a.tiles, batch), dim3(256), 0, s, a);
 }
 
+
+// =====================================================================================================================
+// C2f blocks with a 32-channel hidden width (model.4 and model.15 at a 640 net: 80 x 80) as fused kernels.
+//
+// Per layer these blocks are 4 (n = 1) or 6 (n = 2) launches of small-K convolutions -- K = 288 for the 3x3s, 64..192
+// for the 1x1s -- whose time goes into launch gaps, LDS staging and tensor round trips, not into the matrix cores.
+// Here a workgroup owns an 8 x 16 pixel tile and walks the block's layers with every intermediate in LDS:
+//
+//   mode AB (n = 1)          cv1 on the tile + 2-pixel halo (12 x 20), straight from the block input(s) in memory (two K
+//                            segments, one optionally at half resolution = the neck's upsample + concat) -> y0 (tile), y1
+//                            (halo 2) -> m.0.cv1 on 10 x 18 -> m.0.cv2 (+ y1 if shortcut) on the tile -> cv2 over
+//                            [y0 | y1 | y2] -> block output.  One launch instead of four.
+//   mode A + mode B (n = 2)  A: cv1 -> m.0 -> y0, y1, y2 into the block's concat buffer; B: y2 with halo from there ->
+//                            m.1 -> y3 (LDS only) -> cv2 over [y0 | y1 | y2 | y3].  Two launches instead of six; one fused
+//                            kernel would need a 4-pixel halo and recompute 1.7 x the MFMAs.
+//
+// Planes are [pixel][32 ch] with the 96-byte pixel stride of the LDS conv family (conflict-free ds_read_b128 over 16
+// consecutive pixels); weight fragments of the running layer live in registers, fetched per phase from L1/L2 (direct-
+// family packing).  Rounding points and K order are those of the per-layer kernels (1x1: channels in steps of 32,
+// segment 0 then segment 1; 3x3 with Cin = 32: taps 0..8), so results are bit-identical to them
+// (tests/test_gpu_engine.py::test_fused_kernels_are_bitwise_identical).
+// =====================================================================================================================
+namespace {
+constexpr int FH = kC2f32TileH, FW = kC2f32TileW;       // output tile
+constexpr int R1H = FH + 4, R1W = FW + 4, R1N = R1H * R1W;   // y1 / bottleneck-input region (halo 2): 12 x 20 = 240 = 15 tiles
+constexpr int R2H = FH + 2, R2W = FW + 2, R2N = R2H * R2W;   // bottleneck intermediate (halo 1): 10 x 18 = 180
+constexpr int R3N = FH * FW;                                 // 128 = 8 tiles
+constexpr int PS = 96;                                       // bytes per pixel of a 32-channel plane
+static_assert(R1N % 16 == 0 && R3N % 16 == 0, "tile regions are whole MFMA tiles");
+}  // namespace
+
+// MODE 0 = AB, 1 = A, 2 = B.  KS1 = k-steps of cv1 (Cin / 32).
+template <int MODE, int KS1, bool SHORTCUT>
+__global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *s_in = smem;                         // y1 region (modes AB, A) / y_prev region (mode B)
+    uint8_t *s_t = s_in + R1N * PS;               // bottleneck intermediate
+    uint8_t *s_yn = s_t + R2N * PS;               // bottleneck output on the tile (modes AB, B)
+    uint8_t *s_y0 = s_yn + R3N * PS;              // y0 on the tile (mode AB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int b = blockIdx.y;
+    const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
+    const int oy0 = tyi * FH, ox0 = txi * FW;
+    const int H = a.H, W = a.W;
+    const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    half_t *cat = a.cat + (size_t)b * H * W * a.cat_ld;   // the block's concat buffer [H][W][cat_ld]: y0 | y1 | y2 [| y3]
+
+    if constexpr (MODE != 2) {
+        // ---- 1: cv1 (1x1, Cin -> 64 = y0 | y1, SiLU) on the 12 x 20 region, B fragments straight from memory ----
+        half8 W1[4][KS1];
+        {
+            const half8 *w = reinterpret_cast<const half8 *>(a.w_cv1) + lane;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+                for (int ks = 0; ks < KS1; ks++) W1[nt][ks] = w[(size_t)(nt * KS1 + ks) * 64];
+        }
+        float bias[16];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) bias[u * 8 + i] = a.b_cv1[u * 32 + g * 8 + i];
+        const int H0 = H >> a.s0.shift, W0 = W >> a.s0.shift, H1 = H >> a.s1.shift, W1s = W >> a.s1.shift;
+        for (int t = wave; t < R1N / 16; t += 4) {
+            const int m = t * 16 + r;
+            const int ly = m / R1W, lx = m - ly * R1W;
+            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const int gyc = inside ? gy : 0, gxc = inside ? gx : 0;
+            const half_t *p0 = a.s0.p + ((size_t)(b * H0 + (gyc >> a.s0.shift)) * W0 + (gxc >> a.s0.shift)) * a.s0.ld;
+            const half_t *p1 = a.s1.p + ((size_t)(b * H1 + (gyc >> a.s1.shift)) * W1s + (gxc >> a.s1.shift)) * a.s1.ld;
+            half8 B[KS1];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) {
+                const int c = ks * 32 + 8 * g;
+                B[ks] = zero8;
+                if (inside) B[ks] = *reinterpret_cast<const half8 *>(c < a.s0.C ? p0 + c : p1 + (c - a.s0.C));
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++)
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[nt][ks], B[ks], acc[nt], 0, 0, 0);
+            half8 o[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                o[u] = zero8;   // outside the image y1 is the bottleneck's zero padding
+                if (inside) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        o[u][i] = (half_t)silu(acc[2 * u][i] + bias[u * 8 + i]);
+                        o[u][4 + i] = (half_t)silu(acc[2 * u + 1][i] + bias[u * 8 + 4 + i]);
+                    }
+                }
+            }
+            *reinterpret_cast<half8 *>(s_in + m * PS + g * 16) = o[1];
+            const int cy = ly - 2, cx = lx - 2;
+            if (inside && (unsigned)cy < (unsigned)FH && (unsigned)cx < (unsigned)FW) {
+                if constexpr (MODE == 0) {
+                    *reinterpret_cast<half8 *>(s_y0 + (cy * FW + cx) * PS + g * 16) = o[0];
+                } else {
+                    half_t *q = cat + ((size_t)gy * W + gx) * a.cat_ld + g * 8;
+                    *reinterpret_cast<half8 *>(q) = o[0];
+                    *reinterpret_cast<half8 *>(q + 32) = o[1];
+                }
+            }
+        }
+    } else {
+        // ---- 1': the previous bottleneck's output (slice y_prev of the concat buffer) with a 2-pixel halo -> LDS ----
+        const half_t *src = cat + a.prev_coff;
+        for (int e = tid; e < R1N * 4; e += 256) {
+            const int m = e >> 2, q = e & 3;
+            const int ly = m / R1W, lx = m - ly * R1W;
+            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+            half8 v = zero8;
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const half8 *>(src + ((size_t)gy * W + gx) * a.cat_ld + q * 8);
+            *reinterpret_cast<half8 *>(s_in + m * PS + q * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2: m.cv1 (3x3, 32 -> 32, SiLU) on the 10 x 18 region ----
+    {
+        half8 Wm[2][9];
+        const half8 *w = reinterpret_cast<const half8 *>(a.w_m1) + lane;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) Wm[nt][tap] = w[(size_t)(nt * 9 + tap) * 64];
+        float bias[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) bias[i] = a.b_m1[g * 8 + i];
+        for (int t = wave; t < (R2N + 15) / 16; t += 4) {
+            const int m = t * 16 + r;
+            const bool mv = m < R2N;
+            const int mm = mv ? m : 0;
+            const int ly = mm / R2W, lx = mm - ly * R2W;
+            const uint8_t *base = s_in + (ly * R1W + lx) * PS + g * 16;
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const half8 B = *reinterpret_cast<const half8 *>(base + ((tap / 3) * R1W + (tap % 3)) * PS);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wm[0][tap], B, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wm[1][tap], B, acc1, 0, 0, 0);
+            }
+            if (mv) {
+                const int gy = oy0 - 1 + ly, gx = ox0 - 1 + lx;
+                half8 o = zero8;   // outside the image: the next conv's zero padding
+                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        o[i] = (half_t)silu(acc0[i] + bias[i]);
+                        o[4 + i] = (half_t)silu(acc1[i] + bias[4 + i]);
+                    }
+                }
+                *reinterpret_cast<half8 *>(s_t + m * PS + g * 16) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3: m.cv2 (3x3, 32 -> 32, SiLU) [+ shortcut] on the tile ----
+    {
+        half8 Wm[2][9];
+        const half8 *w = reinterpret_cast<const half8 *>(a.w_m2) + lane;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) Wm[nt][tap] = w[(size_t)(nt * 9 + tap) * 64];
+        float bias[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) bias[i] = a.b_m2[g * 8 + i];
+        for (int t = wave; t < R3N / 16; t += 4) {
+            const int m = t * 16 + r;
+            const int ly = m / FW, lx = m - ly * FW;
+            const uint8_t *base = s_t + (ly * R2W + lx) * PS + g * 16;
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const half8 B = *reinterpret_cast<const half8 *>(base + ((tap / 3) * R2W + (tap % 3)) * PS);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wm[0][tap], B, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wm[1][tap], B, acc1, 0, 0, 0);
+            }
+            half8 o;
+            half8 rv = zero8;
+            if constexpr (SHORTCUT) rv = *reinterpret_cast<const half8 *>(s_in + ((ly + 2) * R1W + lx + 2) * PS + g * 16);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                // the per-layer epilogue adds the shortcut to the ROUNDED activation (separate statements): no fma here
+#pragma clang fp contract(off)
+                const float act = silu((i < 4 ? acc0[i] : acc1[i - 4]) + bias[i]);
+                o[i] = SHORTCUT ? (half_t)(act + (float)rv[i]) : (half_t)act;
+            }
+            if constexpr (MODE == 1) {
+                const int gy = oy0 + ly, gx = ox0 + lx;
+                if (gy < H && gx < W) *reinterpret_cast<half8 *>(cat + ((size_t)gy * W + gx) * a.cat_ld + 64 + g * 8) = o;
+            } else {
+                *reinterpret_cast<half8 *>(s_yn + m * PS + g * 16) = o;
+            }
+        }
+    }
+    if constexpr (MODE == 1) return;
+    __syncthreads();
+
+    // ---- 4: cv2 (1x1 over the concat, -> 64, SiLU) -> block output ----
+    {
+        constexpr int KS2 = MODE == 0 ? 3 : 4;
+        half8 W2[4][KS2];
+        const half8 *w = reinterpret_cast<const half8 *>(a.w_cv2) + lane;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++) W2[nt][ks] = w[(size_t)(nt * KS2 + ks) * 64];
+        float bias[16];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) bias[u * 8 + i] = a.b_cv2[u * 32 + g * 8 + i];
+        half_t *out = a.out + (size_t)b * H * W * a.out_ld;
+        for (int t = wave; t < R3N / 16; t += 4) {
+            const int m = t * 16 + r;
+            const int ly = m / FW, lx = m - ly * FW;
+            const int gy = oy0 + ly, gx = ox0 + lx;
+            const bool inside = gy < H && gx < W;
+            half8 B[KS2];
+            if constexpr (MODE == 0) {
+                B[0] = *reinterpret_cast<const half8 *>(s_y0 + m * PS + g * 16);
+                B[1] = *reinterpret_cast<const half8 *>(s_in + ((ly + 2) * R1W + lx + 2) * PS + g * 16);
+                B[2] = *reinterpret_cast<const half8 *>(s_yn + m * PS + g * 16);
+            } else {
+                // y0, y1 are read once per pixel: straight from the concat buffer; y2 = the staged slice; y3 = this kernel's
+                B[0] = zero8; B[1] = zero8;
+                if (inside) {
+                    const half_t *q = cat + ((size_t)gy * W + gx) * a.cat_ld + g * 8;
+                    B[0] = *reinterpret_cast<const half8 *>(q);
+                    B[1] = *reinterpret_cast<const half8 *>(q + 32);
+                }
+                B[2] = *reinterpret_cast<const half8 *>(s_in + ((ly + 2) * R1W + lx + 2) * PS + g * 16);
+                B[3] = *reinterpret_cast<const half8 *>(s_yn + m * PS + g * 16);
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ks++)
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[nt][ks], B[ks], acc[nt], 0, 0, 0);
+            if (inside) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    half8 o;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        o[i] = (half_t)silu(acc[2 * u][i] + bias[u * 8 + i]);
+                        o[4 + i] = (half_t)silu(acc[2 * u + 1][i] + bias[u * 8 + 4 + i]);
+                    }
+                    *reinterpret_cast<half8 *>(out + ((size_t)gy * W + gx) * a.out_ld + u * 32 + g * 8) = o;
+                }
+            }
+        }
+    }
+}
+
+size_t c2f32_lds_bytes(int mode) { return (size_t)(R1N + R2N + (mode == 1 ? 0 : R3N) + (mode == 0 ? R3N : 0)) * PS; }
+
+bool launch_c2f32(int mode, bool shortcut, const C2f32Args &a, int batch, hipStream_t s)
+{
+    const int ks1 = a.cin1 / 32;
+    const dim3 grid(a.tiles_x * a.tiles_y, batch), block(256);
+    const size_t lds = c2f32_lds_bytes(mode);
+#define IRMV_C2F32(MODE_, KS_, SC_)                                                                               \
+    if (mode == MODE_ && (MODE_ == 2 || ks1 == KS_) && shortcut == SC_) {                                          \
+        static unsigned long long attr_done = 0;                                                                   \
+        int dev = 0; (void)hipGetDevice(&dev);                                                                     \
+        if (!(__atomic_fetch_or(&attr_done, 1ull << (dev & 63), __ATOMIC_RELAXED) & (1ull << (dev & 63))))         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(c2f32_kernel<MODE_, KS_, SC_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+        hipLaunchKernelGGL((c2f32_kernel<MODE_, KS_, SC_>), grid, block, lds, s, a);                               \
+        return true;                                                                                               \
+    }
+    IRMV_C2F32(0, 2, true) IRMV_C2F32(0, 2, false) IRMV_C2F32(0, 4, false) IRMV_C2F32(0, 6, false) IRMV_C2F32(0, 6, true) IRMV_C2F32(0, 4, true)
+    IRMV_C2F32(1, 2, true) IRMV_C2F32(1, 2, false) IRMV_C2F32(1, 4, true) IRMV_C2F32(1, 6, true)
+    IRMV_C2F32(2, 1, true) IRMV_C2F32(2, 1, false)
+#undef IRMV_C2F32
+    return false;
+}
+
 }  // namespace irmv

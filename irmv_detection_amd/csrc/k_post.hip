@@ -93,22 +93,16 @@ __device__ __forceinline__ float dfl_side(const float *l)
     return sj / se;
 }
 
-// Four lanes per (frame, anchor): lane q owns classes 4q..4q+3 and, for anchors with a
-// candidate, box side q (16 DFL logits, one 64-byte read); nothing lives in scratch.
-// The per-side arithmetic is exactly dfl_side().
-__global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
+// Decode phase of nms_pnp_kernel, one quad of lanes per anchor: lane q owns classes 4q..4q+3 (one 16-byte read of the
+// record's class logits) and, for anchors with a candidate, box side q (16 DFL logits, one 64-byte read): the box of an
+// anchor is only ever read for candidates, so 5/6 of the head's bytes are never touched.  The per-side arithmetic is
+// exactly dfl_side().  Candidate keys go to the workgroup's LDS list (and to the frame's global list, which only the
+// > kCandCap path reads back); the list position comes from an LDS counter, so there is no global atomic and no
+// counter that outlives the kernel.
+__device__ __forceinline__ void decode_quad(const PostArgs &a, int b, int quad, bool live, const f32x4 cl, const float *rec, int ix, int iy, int s,
+                                            unsigned long long *skeys, unsigned long long *gk, int *s_ncand)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int quad = t >> 2, q = t & 3;
-    const bool live = quad < batch * a.A;
-    const int qa = live ? quad : 0;
-    const int b = qa / a.A, an = qa - b * a.A;
-    int ix, iy, s, lbase, lhw, rin;
-    anchor_geom(an, a.net, ix, iy, s, lbase, lhw, rin);
-    const float *rec = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
-    // class logits first (64 of the record's 384 bytes).  The box of an anchor is only ever read for anchors that are
-    // candidates, so the four DFL sides (256 bytes) are fetched and decoded just for those: ~6x less head traffic.
-    const f32x4 cl = reinterpret_cast<const f32x4 *>(rec + kClsOff)[q];
+    const int q = threadIdx.x & 3;
     bool hit = false;
 #pragma unroll
     for (int i = 0; i < 4; i++) hit = hit || (live && 4 * q + i < a.nc && cl[i] > a.logit_thr);
@@ -131,7 +125,7 @@ __global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
             box[1] = (ay - dt) * sf;
             box[2] = (ax + dr) * sf;
             box[3] = (ay + db) * sf;
-            reinterpret_cast<f32x4 *>(a.boxes)[quad] = box;
+            reinterpret_cast<f32x4 *>(a.boxes)[(size_t)b * a.A + quad] = box;
         }
     }
     if (!live) return;
@@ -140,18 +134,12 @@ __global__ __launch_bounds__(256) void decode_kernel(PostArgs a, int batch)
         const int c = 4 * q + i;
         const float logit = cl[i];
         if (c < a.nc && logit > a.logit_thr) {
-            const int idx = atomicAdd(&a.counts[b * kCountStride], 1);
-            if (idx < a.key_cap)
-                a.keys[(size_t)b * a.key_cap + idx] =
-                    ((unsigned long long)orderable(logit) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(an * a.nc + c));
+            const int idx = atomicAdd(s_ncand, 1);   // LDS; <= A * nc = key_cap by construction
+            const unsigned long long key = ((unsigned long long)orderable(logit) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(quad * a.nc + c));
+            if (idx < kCandCap) skeys[idx] = key;
+            gk[idx] = key;
         }
     }
-}
-
-void launch_decode(const PostArgs &a, int batch, hipStream_t s)
-{
-    const int total = batch * a.A * 4;
-    hipLaunchKernelGGL(decode_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a, batch);
 }
 
 // "IoU(a, b) > thr" as inter > thr * union (same expression as the oracle's iou_gt)
@@ -245,15 +233,42 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define IRMV_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[b * 8 + (k)] = clock64(); } while (0)
     IRMV_STAMP(0);
-    // the list holds at most key_cap = A * nc pairs; a counter beyond that can only be stale state, and the walk below
-    // must never leave this frame's list whatever the counter says
-    const int n_raw = a.counts[b * kCountStride];
-    const int n_total = n_raw < a.key_cap ? n_raw : a.key_cap;
-    const unsigned long long *gk = a.keys + (size_t)b * a.key_cap;
+    __shared__ int s_ncand;
+    unsigned long long *gk = a.keys + (size_t)b * a.key_cap;
     const unsigned long long *sorted;
     if (tid < 16) cls_cnt[tid] = 0;
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+    // ---- 0. decode: class logits of every anchor -> candidate keys; boxes of candidate anchors ----
+    {
+        constexpr int U = 4;                       // anchors-quads in flight per lane: the loads of U rounds are issued together
+        const int quads_total = a.A * 4;           // 4 lanes per anchor
+        for (int q0 = 0; q0 < quads_total; q0 += 1024 * U) {
+            f32x4 cl[U];
+            const float *rec[U];
+            int ix[U], iy[U], st[U];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = q0 + u * 1024 + tid;
+                live[u] = t < quads_total;
+                const int an = live[u] ? (t >> 2) : 0;
+                int lbase, lhw, rin;
+                anchor_geom(an, a.net, ix[u], iy[u], st[u], lbase, lhw, rin);
+                rec[u] = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
+                cl[u] = reinterpret_cast<const f32x4 *>(rec[u] + kClsOff)[tid & 3];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (q0 + u * 1024 >= quads_total) break;          // workgroup-uniform
+                decode_quad(a, b, (q0 + u * 1024 + tid) >> 2, live[u], cl[u], rec[u], ix[u], iy[u], st[u], skeys, gk, &s_ncand);
+            }
+        }
+    }
+    __syncthreads();   // keys in LDS / global and boxes in global are visible to the whole workgroup from here
+    const int n_total = s_ncand;
     int n_stored = n_total;
-    bool preloaded = false;
+    bool preloaded = n_total <= kCandCap;   // then skeys already holds every key
     if (n_total > kCandCap) {
         // More candidates than the LDS sort holds (noise frames): keep exactly the K = pre_nms_cap largest
         // keys.  Keys are unique, so an 8-pass MSB-first radix select finds the K-th largest key T exactly;
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     if (tid == 0) {
         DevFrameOut fo;
         fo.num_dets = kept;
-        fo.n_candidates = n_raw;
+        fo.n_candidates = n_total;
         fo.overflow = 0;   // (the candidate list is sized for every (anchor, class) pair; kept for ABI stability)
         fo.pad = 0;
         a.fout[b] = fo;
@@ -471,7 +486,6 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         a.dets[(size_t)b * a.max_det + j] = d;
     }
     __syncthreads();
-    if (a.self_reset && tid == 0) a.counts[b * kCountStride] = 0;   // every thread has read it (barriers above): ready for the next step
     IRMV_STAMP(4);
     if (a.dbg && tid == 0) { a.dbg[b * 8 + 5] = n_total; a.dbg[b * 8 + 6] = kept; }
 #undef IRMV_STAMP

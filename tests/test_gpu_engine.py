@@ -3,8 +3,10 @@ reference's YoloEngine / PnPSolver interface), against the CPU oracle.
 
 Stated tolerances (DESIGN.md "Parity"):
   preprocess            bit-exact (integer taps; fp16 of v/255 is unique)
-  activations / head    fp16 storage, fp32 accumulate: |d| <= 3e-2 abs on logits of magnitude ~20
-                        vs the fp32 oracle; same bound vs the fp16-emulating oracle
+  activations / head    fp16 storage, fp32 accumulate: |d| <= 3e-2 abs on logits of magnitude ~20 vs the fp32 oracle
+                        (measured over 11 frames: 0.028; the oracle's own fp16-emulating mode sits 0.029 from its fp32
+                        mode).  Against the fp16-EMULATING oracle the bound is 2 x 3e-2: two fp16 pipelines with
+                        different accumulation orders, each within 3e-2 of the fp32 result (measured 0.036)
   decode / NMS / kpts   bit-exact on identical head tensors (survivor set AND order);
                         end to end vs the fp32 oracle: survivor set IDENTICAL on the margin fixtures
                         (tests/golden/margin_cases.json: every decode / NMS decision clear of fp16 noise), boxes
@@ -97,11 +99,11 @@ def test_network_taps_and_head_vs_oracle(eng, onet, frame0):
         _, t_o = onet.forward(x, emulate_fp16=True, tap=tap)
         t_g = eng.read_tap(tap, 0)
         assert t_g.shape == t_o.shape, tap
-        assert np.abs(t_g - t_o).max() <= HEAD_TOL, tap
+        assert np.abs(t_g - t_o).max() <= 2 * HEAD_TOL, tap     # fp16-emulating oracle: see the module docstring
         assert np.abs(t_g - t_o).mean() <= 2e-3, tap
     h_g = eng.read_head(0)
-    assert np.abs(h_g - onet.forward(x, emulate_fp16=True)).max() <= HEAD_TOL
-    assert np.abs(h_g - onet.forward(x)).max() <= HEAD_TOL           # vs the fp32 oracle
+    assert np.abs(h_g - onet.forward(x)).max() <= HEAD_TOL                            # vs the fp32 oracle: the contract
+    assert np.abs(h_g - onet.forward(x, emulate_fp16=True)).max() <= 2 * HEAD_TOL     # vs another fp16 pipeline
 
 
 def test_network_on_golden_block_input(blob, onet):
@@ -520,12 +522,14 @@ def test_fused_kernels_are_bitwise_identical(blob, monkeypatch, size, net, mode,
             names = [st["name"] for st in e.profile(0, 1)]
             assert ("front_fused" in names) == (env == "1" and fused)
             assert ("c2f2_fused" in names) == (env == "1")
+            assert ("c2f32_ab" in names and "c2f32_a" in names and "c2f32_b" in names) == (env == "1")   # model.15; model.4
             assert any(n.endswith("+1x1") for n in names) == (env == "1")       # Detect finals inside the 3x3 epilogue
             _load(e, 0, img)
             e.detect()
             got.append((e.read_tap("1", 0).copy(), e.read_head(0).copy(), e.read_input(0).copy(), e.read_tap("0", 0).copy(),
                         e.read_tap("2", 0).copy(), e.read_tap("model.2.cat", 0).copy(), e.read_tap("22.cv2.0.1", 0).copy(),
-                        e.read_tap("22.cv3.2.1", 0).copy()))
+                        e.read_tap("22.cv3.2.1", 0).copy(), e.read_tap("4", 0).copy(), e.read_tap("15", 0).copy(),
+                        e.read_tap("model.4.cat", 0).copy(), e.read_tap("model.15.cat", 0).copy(), e.read_tap("model.4.tmp", 0).copy()))
     for a, b in zip(got[0], got[1]):
         assert np.array_equal(a, b)
     assert np.abs(got[0][0]).max() > 0.1
