@@ -90,6 +90,30 @@ static float half_bits_to_float(uint16_t h)
     return f;
 }
 
+// float -> IEEE fp16 bits, round to nearest even (dequantised int8 weights are stored as the fp16 the kernels multiply with)
+static uint16_t float_to_half_bits(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((x > 0x7f800000u) ? 0x200u : 0u));   // inf / nan
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                          // rounds to inf
+    if (x < 0x33000001u) return (uint16_t)sign;                                                        // rounds to zero
+    if (x < 0x38800000u) {   // subnormal half
+        const int shift = 126 - (int)(x >> 23);                     // 14..24
+        const uint32_t man = (x & 0x7fffffu) | 0x800000u;
+        uint32_t h = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((x >> 23) - 112u) << 10 | ((x >> 13) & 0x3ffu);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+
 // ---- engine ----------------------------------------------------------------------
 struct Tensor {
     std::string name;
@@ -199,6 +223,7 @@ struct irmv_engine {
     double last_detect_ms = 0;
     std::vector<uint8_t> blob;
     std::vector<LayerW> layers;
+    std::vector<std::vector<uint16_t>> dequant;   // int8 blobs: per layer fp16(q * scale), what LayerW::w points to
 
     ~irmv_engine();
 };
@@ -832,8 +857,11 @@ static int load_blob(irmv_engine *e)
     if (e->blob.size() < sizeof(BlobHeader)) return fail(IRMV_ERR_MODEL, "weight blob truncated");
     BlobHeader h;
     memcpy(&h, e->blob.data(), sizeof h);
-    if (memcmp(h.magic, "IRMW", 4) != 0 || h.version != 1 || h.dtype != 1 || h.reg_max != 16)
-        return fail(IRMV_ERR_MODEL, "not an IRMW v1 fp16 blob");
+    // dtype 1: fp16 weights.  dtype 2 (BASELINE configs[4], "int8 weights"): int8 OHWI weights + fp32 per-output-channel
+    // scales; expanded here, once, to w = fp16(q * scale) -- the fragment packing below is dtype-agnostic from there on.
+    if (memcmp(h.magic, "IRMW", 4) != 0 || h.version != 1 || (h.dtype != 1 && h.dtype != 2) || h.reg_max != 16)
+        return fail(IRMV_ERR_MODEL, "not an IRMW v1 blob (fp16 or int8 weights)");
+    e->dequant.reserve(h.n_layers);
     if (h.nc < 1 || h.nc > 16 || (h.nk != 0 && h.nk != 8))
         return fail(IRMV_ERR_MODEL, "unsupported head: nc must be 1..16, nk 0 or 8");
     e->nc = (int)h.nc;
@@ -850,9 +878,20 @@ static int load_blob(irmv_engine *e)
         l.name = nm;
         l.cin = bl.cin; l.cout = bl.cout; l.k = bl.k; l.stride = bl.stride; l.act = bl.act;
         const size_t nw = (size_t)l.cout * l.k * l.k * l.cin;
-        if (bl.w_off + nw * 2 > e->blob.size() || bl.b_off + (size_t)l.cout * 4 > e->blob.size())
+        const size_t w_bytes = h.dtype == 2 ? ((nw + 3) & ~(size_t)3) + (size_t)l.cout * 4 : nw * 2;
+        if (bl.w_off + w_bytes > e->blob.size() || bl.b_off + (size_t)l.cout * 4 > e->blob.size())
             return fail(IRMV_ERR_MODEL, "layer " + l.name + " data out of range");
         l.w = reinterpret_cast<const uint16_t *>(e->blob.data() + bl.w_off);
+        if (h.dtype == 2) {
+            const int8_t *q = reinterpret_cast<const int8_t *>(e->blob.data() + bl.w_off);
+            const float *scale = reinterpret_cast<const float *>(e->blob.data() + bl.w_off + ((nw + 3) & ~(size_t)3));
+            e->dequant.emplace_back(nw);
+            std::vector<uint16_t> &d = e->dequant.back();
+            const size_t per_out = nw / l.cout;
+            for (int o = 0; o < l.cout; o++)
+                for (size_t i = 0; i < per_out; i++) d[o * per_out + i] = float_to_half_bits((float)q[o * per_out + i] * scale[o]);
+            l.w = d.data();   // (the vectors were reserved above: no reallocation moves them)
+        }
         l.b = reinterpret_cast<const float *>(e->blob.data() + bl.b_off);
         e->layers.push_back(l);
     }
@@ -959,7 +998,7 @@ static void tune_cache_load()
     int mt, nt, lds, ipw;
     while (f >> key >> mt >> nt >> lds >> ipw) {
         ConvCfg c{};
-        c.mt = mt; c.nt = nt; c.lds = lds != 0; c.ipw = ipw;
+        c.mt = mt; c.nt = nt; c.lds = (lds & 1) != 0; c.deep = (lds & 2) != 0; c.ct = (lds & 4) != 0; c.ipw = ipw;   // bit 0 LDS family, 1 deep prefetch, 2 chunk-major
         g_tune_cache[key] = c;
     }
 }
@@ -970,13 +1009,20 @@ static void tune_cache_save()
     if (!path) return;
     std::lock_guard<std::mutex> lk(g_tune_mu);
     std::ofstream f(path);
-    for (auto &kv : g_tune_cache) f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << (kv.second.lds ? 1 : 0) << ' ' << kv.second.ipw << '\n';
+    for (auto &kv : g_tune_cache)
+        f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0)) << ' ' << kv.second.ipw << '\n';
 }
 
 static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int count, hipStream_t s)
 {
     const int li = c.nt == 4 ? 2 : (c.nt == 2 ? 1 : 0);
     if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s);
+    if (c.ct) {   // direct kernel in the LDS family's K order, on that family's nt = 1 weight packing
+        if (!op.w_lds[0] || a.n2 > 0) return false;
+        ConvArgs a2 = a;
+        a2.w = op.w_lds[0];
+        return launch_conv(c, a2, s);
+    }
     return launch_conv(c, a, s);
 }
 
@@ -1047,15 +1093,19 @@ static int autotune_convs(irmv_engine *e)
                 if (hit != g_tune_cache.end() && !verbose) {
                     const ConvCfg &h = hit->second;
                     const bool pow2 = (h.mt == 1 || h.mt == 2 || h.mt == 4) && (h.nt == 1 || h.nt == 2 || h.nt == 4) && (h.ipw == 1 || h.ipw == 2 || h.ipw == 4);
-                    bool ok = pow2 && op.cout_pad % (16 * h.nt) == 0 && h.ipw <= counts[pass] && h.lds == lds_ok && (!want_fuse || h.nt == 4);
+                    // family: LDS-staged, or (single-frame steps only) its chunk-major stand-in on the direct kernel; never both flags
+                    const bool fam_ok = lds_ok ? ((h.lds && !h.ct && !h.deep) || (!h.lds && h.ct && h.deep && counts[pass] == 1 && !want_fuse))
+                                               : (!h.lds && !h.ct && (!h.deep || counts[pass] == 1));
+                    bool ok = pow2 && op.cout_pad % (16 * h.nt) == 0 && h.ipw <= counts[pass] && fam_ok && (!want_fuse || h.nt == 4);
                     if (ok && h.lds) {
                         const int li = h.nt == 4 ? 2 : (h.nt == 2 ? 1 : 0);
                         ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, h.mt, h.nt, nullptr) > 0;
                     }
                     if (ok && !h.lds) ok = h.ipw == 1;
+                    if (ok && h.deep) ok = (h.mt == 1 || (h.mt == 2 && h.nt == 1)) && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1;
                     if (ok) {
                         best_cfg = op.cfg;
-                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw;
+                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct;
                         best = 0.f;
                         have_hit = true;
                     } else if (getenv("IRMV_AUTOTUNE_VERBOSE") || getenv("IRMV_TUNE_WARN"))
@@ -1063,34 +1113,52 @@ static int autotune_convs(irmv_engine *e)
                 }
             }
             if (!have_hit)
-            for (int fam = lds_ok ? 1 : 0; fam <= (lds_ok ? 1 : 0); fam++)
+            {
+                auto time_cfg = [&](const ConvCfg &c) -> int {
+                    bool ok = true;
+                    for (int i = 0; i < 2 && ok; i++) ok = run_conv(op, c, a, counts[pass], e->stream);
+                    if (!ok) return IRMV_OK;
+                    float ms = 1e30f;   // best of 3 bursts of 4
+                    for (int rep = 0; rep < 3; rep++) {
+                        HIP_TRY(hipEventRecord(ea, e->stream));
+                        for (int i = 0; i < 4; i++) run_conv(op, c, a, counts[pass], e->stream);
+                        HIP_TRY(hipEventRecord(eb, e->stream));
+                        HIP_TRY(hipEventSynchronize(eb));
+                        float t = 0.f;
+                        HIP_TRY(hipEventElapsedTime(&t, ea, eb));
+                        ms = t < ms ? t : ms;
+                    }
+                    if (verbose) {
+                        char nm[48];
+                        cfg_name(c, nm, sizeof nm);
+                        fprintf(stderr, "[autotune] %-22s count=%-2d %-28s %8.2f us\n", op.layer.c_str(), counts[pass], nm, ms / 4 * 1e3);
+                    }
+                    if (ms < best) { best = ms; best_cfg = c; }
+                    return IRMV_OK;
+                };
+                const int fam = lds_ok ? 1 : 0;
                 for (int mt = 1; mt <= 4; mt *= 2)
                     for (int nt = 1; nt <= 4; nt *= 2)
-                    for (int ipw = 1; ipw <= (fam == 1 ? std::min(4, counts[pass]) : 1); ipw *= 2) {
-                        if (op.cout_pad % (16 * nt) != 0) continue;
-                        if (want_fuse && nt != 4) continue;
+                        for (int ipw = 1; ipw <= (fam == 1 ? std::min(4, counts[pass]) : 1); ipw *= 2) {
+                            if (op.cout_pad % (16 * nt) != 0) continue;
+                            if (want_fuse && nt != 4) continue;
+                            ConvCfg c = op.cfg;
+                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false;
+                            TRY(time_cfg(c));
+                        }
+                // single-frame steps: the latency variants of the direct kernel (deep prefetch ring).  For a layer of the LDS
+                // family they walk K in that family's order on its weights (ct), so the family rule above still holds bit for bit.
+                static const bool no_deep = [] { const char *v = getenv("IRMV_NO_DEEP"); return v && v[0] == '1'; }();
+                if (counts[pass] == 1 && !want_fuse && !no_deep && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1 && (!lds_ok || op.w_lds[0])) {
+                    const int tiles[4][2] = {{1, 1}, {2, 1}, {1, 2}, {1, 4}};
+                    for (auto &t : tiles) {
+                        if (op.cout_pad % (16 * t[1]) != 0) continue;
                         ConvCfg c = op.cfg;
-                        c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw;
-                        bool ok = true;
-                        for (int i = 0; i < 2 && ok; i++) ok = run_conv(op, c, a, counts[pass], e->stream);
-                        if (!ok) continue;
-                        float ms = 1e30f;   // best of 3 bursts of 4
-                        for (int rep = 0; rep < 3; rep++) {
-                            HIP_TRY(hipEventRecord(ea, e->stream));
-                            for (int i = 0; i < 4; i++) run_conv(op, c, a, counts[pass], e->stream);
-                            HIP_TRY(hipEventRecord(eb, e->stream));
-                            HIP_TRY(hipEventSynchronize(eb));
-                            float t = 0.f;
-                            HIP_TRY(hipEventElapsedTime(&t, ea, eb));
-                            ms = t < ms ? t : ms;
-                        }
-                        if (verbose) {
-                            char nm[48];
-                            cfg_name(c, nm, sizeof nm);
-                            fprintf(stderr, "[autotune] %-22s count=%-2d %-28s %8.2f us\n", op.layer.c_str(), counts[pass], nm, ms / 4 * 1e3);
-                        }
-                        if (ms < best) { best = ms; best_cfg = c; }
+                        c.mt = t[0]; c.nt = t[1]; c.lds = false; c.ipw = 1; c.deep = true; c.ct = lds_ok;
+                        TRY(time_cfg(c));
                     }
+                }
+            }
             { std::lock_guard<std::mutex> lk(g_tune_mu); g_tune_cache[key] = best_cfg; }
             if (pass == 0) { op.cfg = best_cfg; cfg_name(op.cfg, op.kname, sizeof op.kname); }
             else { op.cfg_one = best_cfg; cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }

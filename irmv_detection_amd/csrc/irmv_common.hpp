@@ -127,7 +127,11 @@ struct ConvArgs {
     int out2_ld, n2;
 };
 
-struct ConvCfg { int ks, stride, mt, nt; bool cin16; int act; bool out_f32; bool lds; int ipw; };   // ipw: images per workgroup (LDS family)
+struct ConvCfg {
+    int ks, stride, mt, nt; bool cin16; int act; bool out_f32; bool lds; int ipw;   // ipw: images per workgroup (LDS family)
+    bool deep;   // direct kernel, latency variant: prefetch ring of 6..12 k-steps (single-frame steps)
+    bool ct;     // direct kernel walking K chunk-major with the LDS family's weights: bit-identical stand-in for that family
+};
 // returns false if no instantiation exists for cfg
 bool launch_conv(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 const char *conv_cfg_name(const ConvCfg &cfg, char *buf, int n);

@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
 #pragma unroll
             for (int i = 0; i < 8; i++) bias[u * 8 + i] = a.b_cv1[u * 32 + g * 8 + i];
         const int H0 = H >> a.s0.shift, W0 = W >> a.s0.shift, H1 = H >> a.s1.shift, W1s = W >> a.s1.shift;
-        for (int t = wave; t < R1N / 16; t += 4) {
+        // the block input is read once per workgroup, straight into B fragments; the next tile's loads are in flight under
+        // this tile's MFMAs and SiLU epilogue (a wave walks ~4 tiles: without this each would expose a full memory round trip)
+        auto load_tile = [&](int t, half8 (&B)[KS1]) {
             const int m = t * 16 + r;
             const int ly = m / R1W, lx = m - ly * R1W;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
@@ -276,13 +278,24 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             const int gyc = inside ? gy : 0, gxc = inside ? gx : 0;
             const half_t *p0 = a.s0.p + ((size_t)(b * H0 + (gyc >> a.s0.shift)) * W0 + (gxc >> a.s0.shift)) * a.s0.ld;
             const half_t *p1 = a.s1.p + ((size_t)(b * H1 + (gyc >> a.s1.shift)) * W1s + (gxc >> a.s1.shift)) * a.s1.ld;
-            half8 B[KS1];
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) {
                 const int c = ks * 32 + 8 * g;
                 B[ks] = zero8;
                 if (inside) B[ks] = *reinterpret_cast<const half8 *>(c < a.s0.C ? p0 + c : p1 + (c - a.s0.C));
             }
+        };
+        half8 Bn[KS1];
+        load_tile(wave, Bn);
+        for (int t = wave; t < R1N / 16; t += 4) {
+            const int m = t * 16 + r;
+            const int ly = m / R1W, lx = m - ly * R1W;
+            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            half8 B[KS1];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) B[ks] = Bn[ks];
+            if (t + 4 < R1N / 16) load_tile(t + 4, Bn);
             f32x4 acc[4];
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -317,13 +330,21 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
     } else {
         // ---- 1': the previous bottleneck's output (slice y_prev of the concat buffer) with a 2-pixel halo -> LDS ----
         const half_t *src = cat + a.prev_coff;
-        for (int e = tid; e < R1N * 4; e += 256) {
+        constexpr int NP = (R1N * 4 + 255) / 256;   // 16-byte pieces per thread: all loads issued before the first LDS store
+        half8 v[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int e = tid + i * 256;
             const int m = e >> 2, q = e & 3;
             const int ly = m / R1W, lx = m - ly * R1W;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            half8 v = zero8;
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const half8 *>(src + ((size_t)gy * W + gx) * a.cat_ld + q * 8);
-            *reinterpret_cast<half8 *>(s_in + m * PS + q * 16) = v;
+            v[i] = zero8;
+            if (e < R1N * 4 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v[i] = *reinterpret_cast<const half8 *>(src + ((size_t)gy * W + gx) * a.cat_ld + q * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int e = tid + i * 256;
+            if (e < R1N * 4) *reinterpret_cast<half8 *>(s_in + (e >> 2) * PS + (e & 3) * 16) = v[i];
         }
     }
     __syncthreads();

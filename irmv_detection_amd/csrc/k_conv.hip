@@ -23,12 +23,19 @@ namespace irmv {
 // CU on the 20x20 / 40x40 layers), so they keep more k-steps of loads in flight.
 template <int MT, int NT>
 struct PrefetchDepth { static constexpr int value = (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4); };
+// Latency variant (single-frame steps: a handful of workgroups per layer, nothing to hide a load behind but the wave's own
+// prefetch): the ring holds 6..12 k-steps, so a K = 1152 layer pays 3 memory round trips instead of 9.
+template <int MT, int NT>
+struct DeepPrefetchDepth { static constexpr int value = (MT + NT <= 2) ? 12 : ((MT + NT <= 3) ? 10 : 6); };
 
-template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32>
+// CT: walk K chunk-major -- k-step s = (32-channel chunk s / 9, tap s % 9), the order of the LDS-staged family below -- with
+// weights in that family's nt = 1 packing, so a 3x3 layer of the LDS family can run on this kernel bit-identically.
+template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32, bool CT = false, bool DEEP = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 {
     constexpr int PAD = KS / 2;
-    constexpr int PF = PrefetchDepth<MT, NT>::value;
+    constexpr int PF = DEEP ? DeepPrefetchDepth<MT, NT>::value : PrefetchDepth<MT, NT>::value;
+    static_assert(!CT || (KS == 3 && !CIN16), "chunk-major order is the 3x3 LDS family's");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
     const int tile0 = (blockIdx.x * 4 + wave) * MT;
@@ -89,6 +96,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                     if (pv[mt]) B[mt] = *reinterpret_cast<const half8 *>(p0[mt] + c);
                 }
             } else {
+                if constexpr (CT) { set_tap(l_ks % 9); l_cc = (l_ks / 9) * 32; }
                 const int c = l_cc + 8 * g;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         }
         // advance
         l_ks++;
-        if constexpr (!CIN16) {
+        if constexpr (!CIN16 && !CT) {
             l_cc += 32;
             if (l_cc >= a.Cin) {
                 l_cc = 0;
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         }
     };
 
-    if constexpr (!CIN16) set_tap(0);
+    if constexpr (!CIN16 && !CT) set_tap(0);
 #pragma unroll
     for (int i = 0; i < PF; i++) load_step(Ab[i], Bb[i]);
     for (int s = 0; s < a.ksteps; s += PF) {
@@ -194,13 +202,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     }
 }
 
-template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32>
+template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32, bool CT = false, bool DEEP = false>
 static void launch_inst(const ConvArgs &a, hipStream_t s)
 {
     const int tiles = (a.M + 15) / 16;
     const int bx = (tiles + 4 * MT - 1) / (4 * MT);
     const int by = a.cout_pad / (16 * NT);
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MT, NT, CIN16, ACT, OUT_F32>), dim3(bx, by), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MT, NT, CIN16, ACT, OUT_F32, CT, DEEP>), dim3(bx, by), dim3(256), 0, s, a);
 }
 
 template <int KS, int STRIDE, bool CIN16, int ACT, bool OUT_F32>
@@ -218,9 +226,31 @@ static bool launch_tile(int mt, int nt, const ConvArgs &a, hipStream_t s)
     return false;
 }
 
+// latency variants (deep prefetch): small tiles only
+template <int KS, int STRIDE, int ACT, bool OUT_F32, bool CT>
+static bool launch_deep(int mt, int nt, const ConvArgs &a, hipStream_t s)
+{
+#define IRMV_DEEP(MT_, NT_)                                                            \
+    if (mt == MT_ && nt == NT_) {                                                      \
+        launch_inst<KS, STRIDE, MT_, NT_, false, ACT, OUT_F32, CT, true>(a, s);        \
+        return true;                                                                   \
+    }
+    IRMV_DEEP(1, 1) IRMV_DEEP(2, 1) IRMV_DEEP(1, 2) IRMV_DEEP(1, 4)
+#undef IRMV_DEEP
+    return false;
+}
+
 bool launch_conv(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
 {
     if (a.cout_pad % (16 * c.nt) != 0) return false;
+    if (c.deep) {
+        // a.w must be the packing that matches the K order: direct packing, or (chunk-major) the LDS family's nt = 1 packing
+        if (c.ks == 3 && c.stride == 1 && c.act == 1 && !c.out_f32 && !c.cin16) return c.ct ? launch_deep<3, 1, 1, false, true>(c.mt, c.nt, a, s) : launch_deep<3, 1, 1, false, false>(c.mt, c.nt, a, s);
+        if (c.ks == 3 && c.stride == 2 && c.act == 1 && !c.out_f32 && !c.cin16) return c.ct ? launch_deep<3, 2, 1, false, true>(c.mt, c.nt, a, s) : launch_deep<3, 2, 1, false, false>(c.mt, c.nt, a, s);
+        if (c.ks == 1 && c.stride == 1 && c.act == 1 && !c.out_f32 && !c.ct) return launch_deep<1, 1, 1, false, false>(c.mt, c.nt, a, s);
+        return false;
+    }
+    if (c.ct) return false;
 #define IRMV_CASE(KS_, ST_, C16_, ACT_, F32_)                                                             \
     if (c.ks == KS_ && c.stride == ST_ && c.cin16 == C16_ && c.act == ACT_ && c.out_f32 == F32_)          \
         return launch_tile<KS_, ST_, C16_, ACT_, F32_>(c.mt, c.nt, a, s);
@@ -236,8 +266,8 @@ bool launch_conv(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
 
 const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 {
-    snprintf(buf, n, "conv%dx%ds%d_mt%d_nt%d%s%s", c.ks, c.ks, c.stride, c.mt, c.nt, c.cin16 ? "_c16" : "",
-             c.out_f32 ? "_f32" : "");
+    snprintf(buf, n, "conv%dx%ds%d_mt%d_nt%d%s%s%s%s", c.ks, c.ks, c.stride, c.mt, c.nt, c.cin16 ? "_c16" : "",
+             c.out_f32 ? "_f32" : "", c.deep ? "_deep" : "", c.ct ? "_ct" : "");
     return buf;
 }
 

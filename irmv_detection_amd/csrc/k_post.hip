@@ -93,22 +93,47 @@ __device__ __forceinline__ float dfl_side(const float *l)
     return sj / se;
 }
 
-// Decode phase of nms_pnp_kernel, one quad of lanes per anchor: lane q owns classes 4q..4q+3 (one 16-byte read of the
-// record's class logits) and, for anchors with a candidate, box side q (16 DFL logits, one 64-byte read): the box of an
-// anchor is only ever read for candidates, so 5/6 of the head's bytes are never touched.  The per-side arithmetic is
-// exactly dfl_side().  Candidate keys go to the workgroup's LDS list (and to the frame's global list, which only the
-// > kCandCap path reads back); the list position comes from an LDS counter, so there is no global atomic and no
-// counter that outlives the kernel.
-__device__ __forceinline__ void decode_quad(const PostArgs &a, int b, int quad, bool live, const f32x4 cl, const float *rec, int ix, int iy, int s,
-                                            unsigned long long *skeys, unsigned long long *gk, int *s_ncand)
+// Decode phase of nms_pnp_kernel, part 1 (scan): one quad of lanes per anchor, lane q owns classes 4q..4q+3 (one 16-byte
+// read of the record's class logits).  Candidate keys go to the workgroup's LDS list (and to the frame's global list,
+// which only the > kCandCap path reads back); anchors with at least one candidate are appended to `alist`.  List
+// positions come from LDS counters: no global atomic, no counter that outlives the kernel.
+__device__ __forceinline__ void scan_quad(const PostArgs &a, int an, bool live, const f32x4 cl, unsigned long long *skeys, unsigned long long *gk,
+                                          int *s_ncand, unsigned short *alist, int *s_nanch)
 {
     const int q = threadIdx.x & 3;
     bool hit = false;
 #pragma unroll
     for (int i = 0; i < 4; i++) hit = hit || (live && 4 * q + i < a.nc && cl[i] > a.logit_thr);
+    if (!__any(hit)) return;                      // the common case: nothing in these 16 anchors
     const int lane = threadIdx.x & 63, base = lane & ~3;
     const bool quad_hit = ((__ballot(hit) >> base) & 0xfull) != 0ull;
-    if (quad_hit) {
+    if (alist && quad_hit && q == 0) alist[atomicAdd(s_nanch, 1)] = (unsigned short)an;
+    if (!hit) return;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = 4 * q + i;
+        const float logit = cl[i];
+        if (c < a.nc && logit > a.logit_thr) {
+            const int idx = atomicAdd(s_ncand, 1);   // LDS; <= A * nc = key_cap by construction
+            const unsigned long long key = ((unsigned long long)orderable(logit) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(an * a.nc + c));
+            if (idx < kCandCap) skeys[idx] = key;
+            gk[idx] = key;
+        }
+    }
+}
+
+// part 2: the box of every anchor on `alist`, four lanes per anchor, lane q decoding side q (16 DFL logits, one 64-byte
+// read; exactly dfl_side()).  Boxes exist only where the NMS walk can read them: 5/6 of the head's bytes are never touched.
+__device__ __forceinline__ void decode_boxes(const PostArgs &a, int b, const unsigned short *alist, int n_anch)
+{
+    const int q = threadIdx.x & 3, lane = threadIdx.x & 63, base = lane & ~3;
+    for (int i0 = 0; i0 < n_anch; i0 += 256) {
+        const int ai = i0 + (threadIdx.x >> 2);
+        const bool live = ai < n_anch;                 // quad-uniform
+        const int an = live ? (alist ? (int)alist[ai] : ai) : 0;   // no list (more anchors than it can index): every anchor
+        int ix, iy, s, lbase, lhw, rin;
+        anchor_geom(an, a.net, ix, iy, s, lbase, lhw, rin);
+        const float *rec = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
         float l[16];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -116,7 +141,6 @@ __device__ __forceinline__ void decode_quad(const PostArgs &a, int b, int quad, 
             l[4 * i] = v[0]; l[4 * i + 1] = v[1]; l[4 * i + 2] = v[2]; l[4 * i + 3] = v[3];
         }
         const float d = dfl_side(l);
-        // the four lanes of a quad are either all here or all not: shuffles inside the branch see live sources
         const float dl = __shfl(d, base), dt = __shfl(d, base + 1), dr = __shfl(d, base + 2), db = __shfl(d, base + 3);
         if (live && q == 0) {
             const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)s;
@@ -125,19 +149,7 @@ __device__ __forceinline__ void decode_quad(const PostArgs &a, int b, int quad, 
             box[1] = (ay - dt) * sf;
             box[2] = (ax + dr) * sf;
             box[3] = (ay + db) * sf;
-            reinterpret_cast<f32x4 *>(a.boxes)[(size_t)b * a.A + quad] = box;
-        }
-    }
-    if (!live) return;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int c = 4 * q + i;
-        const float logit = cl[i];
-        if (c < a.nc && logit > a.logit_thr) {
-            const int idx = atomicAdd(s_ncand, 1);   // LDS; <= A * nc = key_cap by construction
-            const unsigned long long key = ((unsigned long long)orderable(logit) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(quad * a.nc + c));
-            if (idx < kCandCap) skeys[idx] = key;
-            gk[idx] = key;
+            reinterpret_cast<f32x4 *>(a.boxes)[(size_t)b * a.A + an] = box;
         }
     }
 }
@@ -220,9 +232,9 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long skeys[kCandCap];   // 64 KiB: candidate keys (bitonic sorts in place)
     __shared__ unsigned long long srank[kRankSortMax];      // 16 KiB: rank-sort destination
-    __shared__ unsigned long long ssup[kSupCap];            // 32 KiB: intra-block suppression masks
+    __shared__ __attribute__((aligned(16))) unsigned long long ssup[kSupCap];   // 32 KiB: suppression masks (and, before them, the anchor list)
     __shared__ f32x4 stage_box[16][64];                     // 16 KiB: per-wave block staging
-    __shared__ int stage_cls[16][64];
+    __shared__ __attribute__((aligned(16))) int stage_cls[16][64];   // (16-byte aligned: the matrix phase reads it as int4)
     __shared__ f32x4 kept_box[kMaxDetCap];
     __shared__ int kept_cls[kMaxDetCap];
     __shared__ unsigned long long kept_key[kMaxDetCap];
@@ -233,38 +245,45 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define IRMV_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[b * 8 + (k)] = clock64(); } while (0)
     IRMV_STAMP(0);
-    __shared__ int s_ncand;
+    __shared__ int s_ncand, s_nanch;
     unsigned long long *gk = a.keys + (size_t)b * a.key_cap;
     const unsigned long long *sorted;
+    // anchors with a candidate, as 16-bit indices in ssup (free until phase 2): up to 16384 anchors (a 640 net has 8400);
+    // larger nets decode every anchor's box instead
+    unsigned short *alist = a.A <= 4 * kSupCap ? reinterpret_cast<unsigned short *>(ssup) : nullptr;
     if (tid < 16) cls_cnt[tid] = 0;
-    if (tid == 0) s_ncand = 0;
+    if (tid == 0) { s_ncand = 0; s_nanch = 0; }
     __syncthreads();
-    // ---- 0. decode: class logits of every anchor -> candidate keys; boxes of candidate anchors ----
+    // ---- 0. decode.  Scan: class logits of every anchor -> candidate keys + the list of anchors that have one.  Level
+    // by level (records of a level are contiguous), four lanes per anchor; the loads of U rounds are issued together.
     {
-        constexpr int U = 4;                       // anchors-quads in flight per lane: the loads of U rounds are issued together
-        const int quads_total = a.A * 4;           // 4 lanes per anchor
-        for (int q0 = 0; q0 < quads_total; q0 += 1024 * U) {
-            f32x4 cl[U];
-            const float *rec[U];
-            int ix[U], iy[U], st[U];
-            bool live[U];
+        constexpr int U = 8;
+        int lbase = 0;
+#pragma unroll 1
+        for (int l = 0; l < 3; l++) {
+            const int lw = a.net / (8 << l), lhw = lw * lw;
+            const float *lrec = a.head_all + ((size_t)lbase * a.slots_total + (size_t)(a.first + b) * lhw) * kHeadRec;
+            const int quads = lhw * 4;
+            for (int q0 = 0; q0 < quads; q0 += 1024 * U) {
+                f32x4 cl[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int t = q0 + u * 1024 + tid;
-                live[u] = t < quads_total;
-                const int an = live[u] ? (t >> 2) : 0;
-                int lbase, lhw, rin;
-                anchor_geom(an, a.net, ix[u], iy[u], st[u], lbase, lhw, rin);
-                rec[u] = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
-                cl[u] = reinterpret_cast<const f32x4 *>(rec[u] + kClsOff)[tid & 3];
-            }
+                for (int u = 0; u < U; u++) {
+                    const int t = q0 + u * 1024 + tid;
+                    const int rin = t < quads ? (t >> 2) : 0;
+                    cl[u] = reinterpret_cast<const f32x4 *>(lrec + (size_t)rin * kHeadRec + kClsOff)[tid & 3];
+                }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (q0 + u * 1024 >= quads_total) break;          // workgroup-uniform
-                decode_quad(a, b, (q0 + u * 1024 + tid) >> 2, live[u], cl[u], rec[u], ix[u], iy[u], st[u], skeys, gk, &s_ncand);
+                for (int u = 0; u < U; u++) {
+                    if (q0 + u * 1024 >= quads) break;          // workgroup-uniform
+                    const int t = q0 + u * 1024 + tid;
+                    scan_quad(a, lbase + (t >> 2), t < quads, cl[u], skeys, gk, &s_ncand, alist, &s_nanch);
+                }
             }
+            lbase += lhw;
         }
     }
+    __syncthreads();
+    decode_boxes(a, b, alist, alist ? s_nanch : a.A);   // boxes of the candidate anchors, in parallel over the whole workgroup
     __syncthreads();   // keys in LDS / global and boxes in global are visible to the whole workgroup from here
     const int n_total = s_ncand;
     int n_stored = n_total;
@@ -361,6 +380,90 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     const f32x4 *boxes = reinterpret_cast<const f32x4 *>(a.boxes) + (size_t)b * a.A;
     IRMV_STAMP(1);
 
+    constexpr int kMatN = 512, kMatW = kMatN / 64;   // up to this many candidates the FULL suppression matrix fits ssup
+    if (n <= kMatN) {
+        // ---- 2'. full matrix: M[i][w] bit jj <=> candidate j = 64 w + jj (j < i) has my class and IoU(j, i) > thr ----
+        // Every IoU test the greedy walk can need, evaluated up front by the whole workgroup; the walk itself is then
+        // AND / ballot work on 64-bit words (no boxes, no per-class kept lists).  Same comparisons as the oracle's walk.
+        f32x4 *cbox = &stage_box[0][0];      // [1024] -> candidate boxes / classes in sorted order
+        int *ccls = &stage_cls[0][0];
+        __shared__ unsigned long long s_keptw[kMatW];
+        for (int i = tid; i < ((n + 63) & ~63); i += blockDim.x) {
+            if (i < n) {
+                const uint32_t id = 0xffffffffu - (uint32_t)(sorted[i] & 0xffffffffu);
+                cbox[i] = boxes[(int)(id / (uint32_t)a.nc)];
+                ccls[i] = (int)(id % (uint32_t)a.nc);
+            } else {
+                ccls[i] = -1;      // padding up to the block boundary: no class
+            }
+        }
+        if (tid < kMatW) s_keptw[tid] = 0ull;
+        __syncthreads();
+        const int nw = (n + 63) >> 6;
+        for (int item = tid; item < n * nw; item += blockDim.x) {
+            const int w = item / n, i = item - w * n;          // consecutive lanes: consecutive i, same word -> broadcast reads of j
+            unsigned long long mask = 0ull;
+            const int j0 = w << 6;
+            if (j0 < i) {
+                const f32x4 bi = cbox[i];
+                const int ci = ccls[i];
+                const int jend = i - j0 < 64 ? i - j0 : 64;
+                // class filter first, 4 candidates per LDS read (all lanes of a wave read the same words: broadcast), then the
+                // IoU test only for the few same-class candidates
+                unsigned long long same = 0ull;
+#pragma unroll
+                for (int jj = 0; jj < 64; jj += 4) {
+                    const int4 c4 = *reinterpret_cast<const int4 *>(&ccls[j0 + jj]);
+                    same |= (unsigned long long)((c4.x == ci) | ((c4.y == ci) << 1) | ((c4.z == ci) << 2) | ((c4.w == ci) << 3)) << jj;
+                }
+                if (jend < 64) same &= (1ull << jend) - 1ull;
+                while (same) {
+                    const int jj = __ffsll((long long)same) - 1;
+                    same &= same - 1ull;
+                    if (iou_gt(cbox[j0 + jj], bi, a.iou_thr)) mask |= 1ull << jj;
+                }
+            }
+            ssup[i * kMatW + w] = mask;
+        }
+        __syncthreads();
+        IRMV_STAMP(2);
+        // ---- 3'. greedy walk on wave 0, 64 candidates per step ----
+        if (wave == 0) {
+            int kept = 0;
+            for (int start = 0; start < n && kept < a.max_det; start += 64) {
+                const int blk = start >> 6, idx = start + lane;
+                const bool valid = idx < n;
+                bool alive = valid;
+                for (int w = 0; w < blk; w++)                      // suppressed by a kept candidate of an earlier block?
+                    if (valid && (ssup[idx * kMatW + w] & s_keptw[w]) != 0ull) alive = false;
+                const unsigned long long sup = valid ? ssup[idx * kMatW + blk] : 0ull;
+                unsigned long long A = __ballot(alive);
+                int taken = 0;
+                for (unsigned long long todo = A; todo;) {          // walk the still-alive candidates in order
+                    const int j = __ffsll((long long)todo) - 1;
+                    if (kept + taken >= a.max_det) {
+                        A &= (1ull << j) - 1ull;                      // cap reached: drop j and everything after
+                        break;
+                    }
+                    taken++;
+                    const unsigned long long col = __ballot((sup >> j) & 1ull);   // lanes that j suppresses (all > j)
+                    A &= ~col;
+                    todo = A & ~((2ull << j) - 1ull);
+                }
+                const bool mine = (A >> lane) & 1ull;
+                const int pos = kept + __popcll(A & ((1ull << lane) - 1ull));
+                if (mine) {
+                    kept_box[pos] = cbox[idx];
+                    kept_cls[pos] = ccls[idx];
+                    kept_key[pos] = sorted[idx];
+                }
+                if (lane == 0) s_keptw[blk] = A;
+                wave_lds_sync();
+                kept += __popcll(A);
+            }
+            if (lane == 0) s_kept = kept;
+        }
+    } else {
     // ---- 2. intra-block masks, one block per wave ----
     const int n_pre = n < kSupCap ? n : kSupCap;
     for (int start = wave * 64; start < n_pre; start += 16 * 64) {
@@ -425,6 +528,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         }
         if (lane == 0) s_kept = kept;
     }
+    }
     __syncthreads();
     IRMV_STAMP(3);
     const int kept = s_kept;
@@ -436,9 +540,10 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         fo.pad = 0;
         a.fout[b] = fo;
     }
-    // ---- 4. one lane per survivor, spread over the waves (tid = j * 4) so the fp64 PnP lanes do not share a SIMD ----
+    // ---- 4. one QUAD of lanes per survivor: the record is assembled redundantly on its four lanes, the fp64 PnP runs
+    // spread over them (solve_pnp_ippe_quad: one undistorted point / one IPPE solution per lane), lane 0 stores ----
     const int j = tid >> 2;
-    if ((tid & 3) == 0 && j < a.max_det) {
+    if (j < a.max_det) {          // quad-uniform
         DevDet d;
         if (j < kept) {
             const f32x4 box = kept_box[j];
@@ -477,13 +582,13 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             d.armor_valid = a.nk >= 8 ? 1 : 0;   // keypoint head: every detection carries its four points
             d.armor_size = a.armor_size;
             d.n_lights = 0;
-            if (a.nk >= 8) d.pnp_ok = solve_pnp_ippe(*a.pnp, d.kpts, a.armor_size, d.rvec, d.tvec, d.quat) ? 1 : 0;
+            if (a.nk >= 8) d.pnp_ok = solve_pnp_ippe_quad(*a.pnp, d.kpts, a.armor_size, d.rvec, d.tvec, d.quat) ? 1 : 0;
         } else {
             // EfficientNMS zero-pads its outputs
             unsigned char *z = reinterpret_cast<unsigned char *>(&d);
             for (unsigned i = 0; i < sizeof(DevDet); i++) z[i] = 0;
         }
-        a.dets[(size_t)b * a.max_det + j] = d;
+        if ((tid & 3) == 0) a.dets[(size_t)b * a.max_det + j] = d;
     }
     __syncthreads();
     IRMV_STAMP(4);

@@ -190,4 +190,122 @@ __device__ inline bool solve_pnp_ippe(const PnpConst &c, const float *pts, int a
     return chk == chk && fabs(chk) < 1e300;
 }
 
+// The same solver spread over a QUAD of lanes (4 consecutive lanes, all active, same arguments; the result is valid on
+// every lane of the quad).  The two data-parallel parts run one item per lane -- the four points of the iterative
+// undistortion, the two IPPE solutions -- everything else is computed redundantly in lockstep.  Per point / per solution
+// the operation sequence is the one of solve_pnp_ippe(), so the results are bit-identical to it; degenerate inputs are
+// carried as a flag instead of early returns so that the shuffles stay converged.
+__device__ inline double quad_bcast(double v, int src_lane) { return __shfl(v, src_lane); }
+
+__device__ inline bool solve_pnp_ippe_quad(const PnpConst &c, const float *pts, int armor_size, double *rvec, double *tvec, double *quat)
+{
+    const int lane = threadIdx.x & 63, base = lane & ~3, q = lane & 3;
+    const double hy = c.hy[armor_size], hz = c.hz[armor_size];
+    bool ok = true;
+    double nxy[8];
+    {   // point q on this lane (undistort4's loop body)
+        const double x0 = ((double)pts[2 * q] - c.cx) / c.fx, y0 = ((double)pts[2 * q + 1] - c.cy) / c.fy;
+        double x = x0, y = y0;
+        for (int it = 0; it < 5; it++) {
+            const double r2 = x * x + y * y;
+            const double icd = 1.0 / (1.0 + ((c.k3 * r2 + c.k2) * r2 + c.k1) * r2);
+            const double dx = 2.0 * c.p1 * x * y + c.p2 * (r2 + 2.0 * x * x);
+            const double dy = c.p1 * (r2 + 2.0 * y * y) + 2.0 * c.p2 * x * y;
+            x = (x0 - dx) * icd;
+            y = (y0 - dy) * icd;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            nxy[2 * i] = quad_bcast(x, base + i);
+            nxy[2 * i + 1] = quad_bcast(y, base + i);
+        }
+    }
+    const double cX[4] = {hy, hy, -hy, -hy}, cY[4] = {-hz, hz, hz, -hz};
+    const double x0 = nxy[0], y0 = nxy[1], x1 = nxy[6], y1 = nxy[7], x2 = nxy[4], y2 = nxy[5], x3 = nxy[2], y3 = nxy[3];
+    const double dx1 = x1 - x2, dx2 = x3 - x2, sx = x0 - x1 + x2 - x3;
+    const double dy1 = y1 - y2, dy2 = y3 - y2, sy = y0 - y1 + y2 - y3;
+    double den = dx1 * dy2 - dy1 * dx2;
+    if (!(fabs(den) > 1e-300)) { ok = false; den = 1.0; }
+    const double gg = (sx * dy2 - dx2 * sy) / den, hh = (dx1 * sy - sx * dy1) / den;
+    const double sa = x1 - x0 + gg * x1, sb = x3 - x0 + hh * x3, sc = x0;
+    const double sd = y1 - y0 + gg * y1, se = y3 - y0 + hh * y3, sf = y0;
+    const double iu = -0.5 / hy, iv = 0.5 / hz;
+    double H[9] = {sa * iu, sb * iv, 0.5 * sa + 0.5 * sb + sc,
+                   sd * iu, se * iv, 0.5 * sd + 0.5 * se + sf,
+                   gg * iu, hh * iv, 0.5 * gg + 0.5 * hh + 1.0};
+    if (!(fabs(H[8]) > 1e-300)) { ok = false; H[8] = 1.0; }
+    const double ih = 1.0 / H[8];
+    for (int i = 0; i < 9; i++) H[i] *= ih;
+    const double p = H[2], qq = H[5];
+    const double j00 = H[0] - H[6] * p, j01 = H[1] - H[7] * p, j10 = H[3] - H[6] * qq, j11 = H[4] - H[7] * qq;
+    double rv[9];
+    const double s = sqrt(p * p + qq * qq + 1.0), t = sqrt(p * p + qq * qq);
+    const double costh = 1.0 / s, sinth = sqrt(1.0 - 1.0 / (s * s));
+    if (t < 1e-300) {
+        rv[0] = 1; rv[1] = 0; rv[2] = 0; rv[3] = 0; rv[4] = 1; rv[5] = 0; rv[6] = 0; rv[7] = 0; rv[8] = 1;
+    } else {
+        const double k0 = p / t, k1 = qq / t;
+        rv[0] = (costh - 1.0) * k0 * k0 + 1.0; rv[1] = k0 * k1 * (costh - 1.0); rv[2] = k0 * sinth;
+        rv[3] = rv[1]; rv[4] = (costh - 1.0) * k1 * k1 + 1.0; rv[5] = k1 * sinth;
+        rv[6] = -k0 * sinth; rv[7] = -k1 * sinth; rv[8] = (costh - 1.0) * (k0 * k0 + k1 * k1) + 1.0;
+    }
+    const double b00 = rv[0] - p * rv[6], b01 = rv[1] - p * rv[7], b10 = rv[3] - qq * rv[6], b11 = rv[4] - qq * rv[7];
+    double bdet = b00 * b11 - b01 * b10;
+    if (!(fabs(bdet) > 1e-300)) { ok = false; bdet = 1.0; }
+    const double dti = 1.0 / bdet;
+    const double a00 = dti * (b11 * j00 - b01 * j10), a01 = dti * (b11 * j01 - b01 * j11);
+    const double a10 = dti * (-b10 * j00 + b00 * j10), a11 = dti * (-b10 * j01 + b00 * j11);
+    const double ata00 = a00 * a00 + a01 * a01, ata01 = a00 * a10 + a01 * a11, ata11 = a10 * a10 + a11 * a11;
+    double g2 = 0.5 * (ata00 + ata11 + sqrt((ata00 - ata11) * (ata00 - ata11) + 4.0 * ata01 * ata01));
+    if (!(g2 > 0.0)) { ok = false; g2 = 1.0; }
+    const double gam = sqrt(g2);
+    const double r00 = a00 / gam, r01 = a01 / gam, r10 = a10 / gam, r11 = a11 / gam;
+    const double bb0 = sqrt(fmax(1.0 - r00 * r00 - r10 * r10, 0.0));
+    double bb1 = sqrt(fmax(1.0 - r01 * r01 - r11 * r11, 0.0));
+    if (-r00 * r01 - r10 * r11 < 0.0) bb1 = -bb1;
+
+    // solution (q & 1) on this lane
+    Pose ps;
+    bool sol_ok;
+    {
+        const int sol = q & 1;
+        const double c0 = sol ? -bb0 : bb0, c1 = sol ? -bb1 : bb1;
+        const double m[9] = {r00, r01, r10 * c1 - c0 * r11, r10, r11, c0 * r01 - r00 * c1, c0, c1, r00 * r11 - r01 * r10};
+        double Rc[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Rc[i * 3 + j] = rv[i * 3] * m[j] + rv[i * 3 + 1] * m[3 + j] + rv[i * 3 + 2] * m[6 + j];
+        sol_ok = ippe_translation(cX, cY, nxy, Rc, ps.t);
+        if (!sol_ok) { ps.t[0] = ps.t[1] = 0.0; ps.t[2] = 1.0; }
+        double e = 0.0;
+        for (int i = 0; i < 4; i++) {
+            const double X = Rc[0] * cX[i] + Rc[1] * cY[i] + ps.t[0];
+            const double Y = Rc[3] * cX[i] + Rc[4] * cY[i] + ps.t[1];
+            const double Z = Rc[6] * cX[i] + Rc[7] * cY[i] + ps.t[2];
+            const double ex = X / Z - nxy[2 * i], ey = Y / Z - nxy[2 * i + 1];
+            e += ex * ex + ey * ey;
+        }
+        ps.err = sqrt(e / 8.0);
+        for (int i = 0; i < 3; i++) {
+            ps.R[i * 3 + 0] = Rc[i * 3 + 2];
+            ps.R[i * 3 + 1] = Rc[i * 3 + 0];
+            ps.R[i * 3 + 2] = Rc[i * 3 + 1];
+        }
+    }
+    // solve_pnp_ippe(): a failed translation of EITHER solution fails the call; else `best` = solution 0 unless !(err0 <= err1)
+    const int ok0 = __shfl((int)sol_ok, base), ok1 = __shfl((int)sol_ok, base + 1);
+    const double e0 = quad_bcast(ps.err, base), e1 = quad_bcast(ps.err, base + 1);
+    ok = ok && ok0 && ok1;
+    const int win = base + ((e0 <= e1) ? 0 : 1);
+    Pose best;
+#pragma unroll
+    for (int i = 0; i < 9; i++) best.R[i] = quad_bcast(ps.R[i], win);
+#pragma unroll
+    for (int i = 0; i < 3; i++) best.t[i] = quad_bcast(ps.t[i], win);
+    rot_to_rvec(best.R, rvec);
+    tvec[0] = best.t[0]; tvec[1] = best.t[1]; tvec[2] = best.t[2];
+    if (quat) rot_to_quat(best.R, quat);
+    const double chk = rvec[0] + rvec[1] + rvec[2] + tvec[0] + tvec[1] + tvec[2];
+    return ok && chk == chk && fabs(chk) < 1e300;
+}
+
 }  // namespace irmv

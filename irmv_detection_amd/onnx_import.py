@@ -167,12 +167,15 @@ def write_initializer_only_onnx(tensors: Dict[str, np.ndarray]) -> bytes:
 
 
 def main(argv):
-    if len(argv) != 2:
+    args = [a for a in argv[1:] if a != "--int8"]
+    if len(args) != 1:
         print(__doc__)
         return 2
-    src = argv[1]
+    src = args[0]
     with open(src, "rb") as f:
         blob = convert(f.read())
+    if "--int8" in argv:      # per-output-channel int8 weights (BASELINE configs[4]); biases stay fp32
+        blob = weights.quantize_blob_int8(blob)
     dst = weights.model_blob_path(src)
     with open(dst, "wb") as f:
         f.write(blob)

@@ -73,20 +73,73 @@ def build_blob(specs: List[arch.ConvSpec], tensors: List[Tuple[np.ndarray, np.nd
     return bytes(buf)
 
 
+DTYPE_FP16, DTYPE_INT8 = 1, 2
+
+
 def parse_blob(blob: bytes):
-    """-> (header dict, [(ConvSpec, w fp16 OHWI, b fp32)])."""
+    """-> (header dict, [(ConvSpec, w fp16 OHWI, b fp32)]).  An int8 blob (dtype 2) is returned DEQUANTISED: the fp16
+    weights every consumer (engine, oracle) computes with, w = fp16(q * scale)."""
     magic, ver, nc, nk, reg_max, n_layers, dtype, _ = struct.unpack_from(HEADER_FMT, blob, 0)
-    if magic != MAGIC or ver != VERSION or dtype != 1:
-        raise ValueError("not an IRMW v1 fp16 blob")
+    if magic != MAGIC or ver != VERSION or dtype not in (DTYPE_FP16, DTYPE_INT8):
+        raise ValueError("not an IRMW v1 blob (fp16 or int8 weights)")
     out = []
     for i in range(n_layers):
         name, cin, cout, k, stride, act, _, w_off, b_off = struct.unpack_from(
             LAYER_FMT, blob, HEADER_SIZE + i * LAYER_SIZE)
         sp = arch.ConvSpec(name.rstrip(b"\0").decode(), cin, cout, k, stride, act)
-        w = np.frombuffer(blob, np.float16, sp.n_weights, w_off).reshape(cout, k, k, cin)
+        if dtype == DTYPE_FP16:
+            w = np.frombuffer(blob, np.float16, sp.n_weights, w_off).reshape(cout, k, k, cin)
+        else:
+            q = np.frombuffer(blob, np.int8, sp.n_weights, w_off).reshape(cout, k, k, cin)
+            scale = np.frombuffer(blob, np.float32, cout, w_off + _align(sp.n_weights, 4))
+            w = (q.astype(np.float32) * scale[:, None, None, None]).astype(np.float16)
         b = np.frombuffer(blob, np.float32, cout, b_off)
         out.append((sp, w, b))
-    return dict(nc=nc, nk=nk, reg_max=reg_max, n_layers=n_layers), out
+    return dict(nc=nc, nk=nk, reg_max=reg_max, n_layers=n_layers, dtype=dtype), out
+
+
+def quantize_int8(w: np.ndarray):
+    """Per-output-channel symmetric int8: scale[o] = max|w[o]| / 127, q = round(w / scale) in [-127, 127].
+    -> (q int8 OHWI, scale fp32 [cout]).  |w - q * scale| <= scale / 2 element-wise."""
+    w32 = np.asarray(w, np.float32)
+    amax = np.abs(w32).reshape(w32.shape[0], -1).max(axis=1)
+    scale = np.where(amax > 0, amax / 127.0, 1.0).astype(np.float32)
+    q = np.clip(np.rint(w32 / scale[:, None, None, None]), -127, 127).astype(np.int8)
+    return q, scale
+
+
+def build_blob_int8(specs: List[arch.ConvSpec], tensors: List[Tuple[np.ndarray, np.ndarray]], nc: int, nk: int) -> bytes:
+    """.irmw with dtype 2 (BASELINE configs[4]: int8 weights): per layer int8 OHWI weights followed (4-byte aligned) by
+    the fp32 per-output-channel scales; biases stay fp32.  Half the bytes of the fp16 blob on disk, over the RCCL
+    broadcast and in the host->device upload; the engine expands w = fp16(q * scale) once at load into the MFMA fragment
+    layout, so the kernels and their fp16-multiply / fp32-accumulate arithmetic are the fp16 model's."""
+    off = _align(HEADER_SIZE + LAYER_SIZE * len(specs))
+    table, chunks = [], []
+    for sp, (w, b) in zip(specs, tensors):
+        q, scale = quantize_int8(w)
+        w_off = off
+        off = _align(off + _align(sp.n_weights, 4) + 4 * sp.cout)
+        b_off = off
+        off = _align(off + 4 * sp.cout)
+        table.append(struct.pack(LAYER_FMT, sp.name.encode(), sp.cin, sp.cout, sp.k, sp.stride, sp.act, 0, w_off, b_off))
+        chunks.append((w_off, q.tobytes()))
+        chunks.append((w_off + _align(sp.n_weights, 4), scale.tobytes()))
+        chunks.append((b_off, np.asarray(b, np.float32).tobytes()))
+    buf = bytearray(off)
+    buf[:HEADER_SIZE] = struct.pack(HEADER_FMT, MAGIC, VERSION, nc, nk, arch.REG_MAX, len(specs), DTYPE_INT8, 0)
+    p = HEADER_SIZE
+    for t in table:
+        buf[p:p + LAYER_SIZE] = t
+        p += LAYER_SIZE
+    for o, data in chunks:
+        buf[o:o + len(data)] = data
+    return bytes(buf)
+
+
+def quantize_blob_int8(blob: bytes) -> bytes:
+    """fp16 .irmw -> int8 .irmw (same layers, biases, head)."""
+    hdr, layers = parse_blob(blob)
+    return build_blob_int8([sp for sp, _, _ in layers], [(w, b) for _, w, b in layers], hdr["nc"], hdr["nk"])
 
 
 def load_calib() -> Optional[dict]:

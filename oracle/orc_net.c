@@ -105,7 +105,8 @@ orc_net *orc_net_load(const uint8_t *blob, size_t bytes)
     if (bytes < sizeof(struct blob_header)) return NULL;
     struct blob_header h;
     memcpy(&h, blob, sizeof h);
-    if (memcmp(h.magic, "IRMW", 4) != 0 || h.version != 1 || h.dtype != 1 || h.reg_max != 16)
+    /* dtype 1: fp16 weights; dtype 2: int8 weights + fp32 per-output-channel scales, used as w = fp16(q * scale) */
+    if (memcmp(h.magic, "IRMW", 4) != 0 || h.version != 1 || (h.dtype != 1 && h.dtype != 2) || h.reg_max != 16)
         return NULL;
     orc_net *n = calloc(1, sizeof *n);
     n->nc = (int)h.nc;
@@ -120,19 +121,24 @@ orc_net *orc_net_load(const uint8_t *blob, size_t bytes)
         c->name[31] = 0;
         c->cin = l.cin; c->cout = l.cout; c->k = l.k; c->stride = l.stride; c->act = l.act;
         size_t nw = (size_t)c->cout * c->k * c->k * c->cin;
-        if (l.w_off + nw * 2 > bytes || l.b_off + (size_t)c->cout * 4 > bytes) {
+        const size_t w_bytes = h.dtype == 2 ? ((nw + 3) & ~(size_t)3) + (size_t)c->cout * 4 : nw * 2;
+        if (l.w_off + w_bytes > bytes || l.b_off + (size_t)c->cout * 4 > bytes) {
             orc_net_free(n);
             return NULL;
         }
         c->w = malloc(nw * sizeof(float));
         c->b = malloc((size_t)c->cout * sizeof(float));
         const uint16_t *wh = (const uint16_t *)(blob + l.w_off); /* OHWI */
+        const int8_t *wq = (const int8_t *)(blob + l.w_off);
+        const float *scale = (const float *)(blob + l.w_off + ((nw + 3) & ~(size_t)3));
         int taps = c->k * c->k;
         for (int o = 0; o < c->cout; o++)
             for (int t = 0; t < taps; t++)
-                for (int ci = 0; ci < c->cin; ci++)
+                for (int ci = 0; ci < c->cin; ci++) {
+                    const size_t src = ((size_t)o * taps + t) * c->cin + ci;
                     c->w[((size_t)t * c->cin + ci) * c->cout + o] =
-                        f16_bits_to_f32(wh[((size_t)o * taps + t) * c->cin + ci]);
+                        h.dtype == 2 ? orc_round_f16((float)wq[src] * scale[o]) : f16_bits_to_f32(wh[src]);
+                }
         memcpy(c->b, blob + l.b_off, (size_t)c->cout * 4);
     }
     return n;

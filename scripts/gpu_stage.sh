@@ -42,6 +42,39 @@ traffic) cd /tmp; export TMPDIR=/tmp
          python3 scripts/collect_traffic.py $O/pmc_f/*/*_counter_collection.csv $O/pmc_w/*/*_counter_collection.csv $O/traffic.json ;;
 probe)   run probe_build 120 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 scripts/probes/stream_probe.cpp -o $O/stream_probe
          run stream_probe 200 $O/stream_probe ;;
+trace1)  cd /tmp; export TMPDIR=/tmp
+         TAG=trace run trace1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/scripts/lat_probe.py
+         cd $R
+         python3 - <<'PY' > $O/trace1_summary.txt 2>&1
+import csv, glob, collections
+f = glob.glob('$O/trace1/*/*_kernel_trace.csv')[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+# the last 65-kernel-ish steps: take the final 2000 dispatches, report per-kernel mean duration and mean gap to the previous kernel
+tail = rows[-2000:]
+d = collections.defaultdict(list); g = []
+for a, b in zip(tail, tail[1:]):
+    g.append(int(b['Start_Timestamp']) - int(a['End_Timestamp']))
+for r in tail:
+    d[r['Kernel_Name'][:70]].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+import statistics
+print('mean kernel duration ns', statistics.mean(x for v in d.values() for x in v), 'median gap ns', statistics.median(g), 'mean gap ns (gaps < 20 us)', statistics.mean(x for x in g if x < 20000))
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:40]:
+    print(f'{k:72s} n={len(v):5d} mean {statistics.mean(v)/1000:7.2f} us')
+PY
+         cat $O/trace1_summary.txt | head -50 ;;
+hostprobe) run host_probe 500 python3 scripts/host_probe.py ;;
+crashprobe) cd /tmp; export TMPDIR=/tmp
+         for v in inline nozc default; do
+           case $v in default) E="";; inline) E="IRMV_INLINE_COPIES=1";; nozc) E="IRMV_ZERO_COPY_RESULTS=0";; esac
+           echo "=== crashprobe $v" | tee -a $O/stages.log
+           env TAG=$v $E timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/crash_$v -- python3 $R/scripts/prof_crash_probe.py > $O/crash_$v.log 2>&1
+           rc=$?; echo "=== crashprobe $v exit $rc" | tee -a $O/stages.log
+           grep "^\[" $O/crash_$v.log
+           if [ $rc -ge 124 ]; then echo "crashprobe $v died: stopping the chain" | tee -a $O/stages.log; exit $rc; fi
+         done
+         cd $R ;;
+stamps)  TAG=stamps IRMV_NMS_STAMPS=1 run nms_stamps 200 python3 scripts/lat_probe.py ;;
 headerr) run head_error 400 python3 scripts/head_error.py ;;
 lat)     TAG=linear run lat_linear 200 python3 scripts/lat_probe.py
          TAG=fork_head IRMV_FORK_HEAD=1 run lat_fork 200 python3 scripts/lat_probe.py ;;
