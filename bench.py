@@ -74,7 +74,7 @@ def parse_args():
     ap.add_argument("--src", default="1280x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96)
-    ap.add_argument("--host-group", type=int, default=16, help="slots per upload group of the host-inclusive leg")
+    ap.add_argument("--host-group", type=int, default=32, help="slots per upload group of the host-inclusive leg")
     return ap.parse_args()
 
 
@@ -124,15 +124,37 @@ def dbg(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+class _Solo:
+    """The distributed helpers at world size 1, without importing torch: a torch HIP context in the process slows every
+    HIP call of the hand-off path (measured on the GPU box, scripts/host_probe.py: host-inclusive 13.8 k -> 7.9 k FPS at
+    16-slot upload groups, host submit time x 2.3).  torch is plumbing for N > 1 (torch.distributed over RCCL) only."""
+    @staticmethod
+    def barrier(): pass
+    @staticmethod
+    def max_over_ranks(x, dev): return float(x)
+    @staticmethod
+    def shard_frames(total, rank, world): return list(range(rank, total, world))
+    @staticmethod
+    def device_index(local_rank):
+        forced = os.environ.get("IRMV_FORCE_DEVICE")
+        return int(forced) if forced is not None else local_rank
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
-    import torch
-    from irmv_detection_amd import arch, dist as D, frames as F, weights
+    from irmv_detection_amd import arch, capi, frames as F, weights
     from irmv_detection_amd.engine import DEFAULT_CAMERA_MATRIX, DEFAULT_DIST_COEFFS, YoloEngine
 
-    rank, local_rank, world = D.init()
+    solo = int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("IRMV_BENCH_TORCH")
+    if solo:
+        D, torch = _Solo, None
+        rank, local_rank, world = 0, 0, 1
+    else:
+        import torch
+        from irmv_detection_amd import dist as D
+        rank, local_rank, world = D.init()
     # Tile choices: seed the autotuner from the table measured for this build (profiles/r01_tune_cache.txt) so that every
     # run and every rank replays the same, bitwise-neutral choices; layers missing from it are tuned on the spot.  Each
     # rank works on its own copy (the engine rewrites the file it is given).
@@ -148,20 +170,34 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python bench.py --gpus N starts them itself)")
-    if not torch.cuda.is_available():
+    ndev = capi.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dev_idx = D.device_index(local_rank)
-    torch.cuda.set_device(dev_idx)
-    dev = torch.device("cuda", dev_idx)
+    if torch is not None:
+        torch.cuda.set_device(dev_idx)
+        dev = torch.device("cuda", dev_idx)
+    else:
+        dev = None
+
+    def device_sync():
+        """hipDeviceSynchronize on this rank's GPU: torch.cuda.synchronize() where torch is in the process (N > 1), the same
+        call through the C ABI otherwise."""
+        if torch is not None:
+            torch.cuda.synchronize()
+        else:
+            capi.device_synchronize(dev_idx)
     sw, sh = (int(v) for v in args.src.lower().split("x"))
     B = args.frames_per_step
 
     # weights: rank 0 generates, everyone receives by ONE broadcast (RCCL over xGMI)
     blob = weights.synthetic_blob(0) if rank == 0 else None
-    wt = D.broadcast_blob(blob, dev)
-    torch.cuda.synchronize()
-    eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(),
-                     num_slots=B)
+    if torch is not None:
+        wt = D.broadcast_blob(blob, dev)
+        torch.cuda.synchronize()
+        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=B)
+    else:
+        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=B)
 
     # this rank's frames: round-robin over the global frame index, made resident in HBM once
     my = D.shard_frames(B * world, rank, world)
@@ -178,12 +214,12 @@ def main():
     dbg("timed loop")
 
     D.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.submit(0, B, h2d=False)
     eng.wait()
-    torch.cuda.synchronize()
+    device_sync()
     dt = time.perf_counter() - t0
     D.barrier()
     dt_max = D.max_over_ranks(dt, dev)
@@ -212,13 +248,13 @@ def main():
         eng.wait()
         hsteps = max(10, args.steps // 4)
         D.barrier()
-        torch.cuda.synchronize()
+        device_sync()
         t1 = time.perf_counter()
         for _ in range(hsteps):
             for f, c in groups:
                 eng.submit(f, c, h2d=True, async_upload=True)   # upload stream: overlaps other groups' kernels
         eng.wait()
-        torch.cuda.synchronize()
+        device_sync()
         dth = time.perf_counter() - t1
         D.barrier()
         dth = D.max_over_ranks(dth, dev)
@@ -364,7 +400,7 @@ def main():
     D.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch is not None and world > 1:
         torch.distributed.destroy_process_group()
 
 

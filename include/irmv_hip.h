@@ -139,6 +139,7 @@ typedef struct irmv_kernel_stat {
 const char *irmv_last_error(void);
 const char *irmv_version(void);
 int irmv_device_count(int *count);
+int irmv_device_synchronize(int device);   /* hipDeviceSynchronize on that device */
 
 void irmv_engine_cfg_default(irmv_engine_cfg *cfg);
 int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out);

@@ -74,6 +74,7 @@ SYMBOLS = [
     ("irmv_last_error", C.c_char_p, []),
     ("irmv_version", C.c_char_p, []),
     ("irmv_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("irmv_device_synchronize", C.c_int, [C.c_int]),
     ("irmv_engine_cfg_default", None, [C.POINTER(EngineCfg)]),
     ("irmv_engine_create", C.c_int, [C.POINTER(EngineCfg), C.POINTER(_P)]),
     ("irmv_engine_destroy", None, [_P]),
@@ -141,3 +142,13 @@ def device_count() -> int:
     n = C.c_int(0)
     check(load().irmv_device_count(C.byref(n)))
     return n.value
+
+
+def device_count() -> int:
+    """HIP devices visible to this process (0 without a GPU)."""
+    n = C.c_int(0)
+    return n.value if load().irmv_device_count(C.byref(n)) == OK else 0
+
+
+def device_synchronize(device: int = 0) -> None:
+    check(load().irmv_device_synchronize(device))

@@ -52,6 +52,12 @@ static int fail(int code, const std::string &msg)
 
 extern "C" const char *irmv_last_error(void) { return g_err.c_str(); }
 extern "C" const char *irmv_version(void) { return "irmv_hip 0.1 (gfx950)"; }
+extern "C" int irmv_device_synchronize(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return IRMV_OK;
+}
 extern "C" int irmv_device_count(int *count)
 {
     if (!count) return fail(IRMV_ERR_ARG, "count is null");
@@ -1094,7 +1100,7 @@ static int autotune_convs(irmv_engine *e)
                     const ConvCfg &h = hit->second;
                     const bool pow2 = (h.mt == 1 || h.mt == 2 || h.mt == 4) && (h.nt == 1 || h.nt == 2 || h.nt == 4) && (h.ipw == 1 || h.ipw == 2 || h.ipw == 4);
                     // family: LDS-staged, or (single-frame steps only) its chunk-major stand-in on the direct kernel; never both flags
-                    const bool fam_ok = lds_ok ? ((h.lds && !h.ct && !h.deep) || (!h.lds && h.ct && h.deep && counts[pass] == 1 && !want_fuse))
+                    const bool fam_ok = lds_ok ? ((h.lds && !h.ct && !h.deep) || (!h.lds && h.ct && !want_fuse && (!h.deep || counts[pass] == 1)))
                                                : (!h.lds && !h.ct && (!h.deep || counts[pass] == 1));
                     bool ok = pow2 && op.cout_pad % (16 * h.nt) == 0 && h.ipw <= counts[pass] && fam_ok && (!want_fuse || h.nt == 4);
                     if (ok && h.lds) {
@@ -1103,6 +1109,7 @@ static int autotune_convs(irmv_engine *e)
                     }
                     if (ok && !h.lds) ok = h.ipw == 1;
                     if (ok && h.deep) ok = (h.mt == 1 || (h.mt == 2 && h.nt == 1)) && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1;
+                    if (ok && h.ct) ok = op.w_lds[0] != nullptr;
                     if (ok) {
                         best_cfg = op.cfg;
                         best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct;
@@ -1146,8 +1153,17 @@ static int autotune_convs(irmv_engine *e)
                             c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false;
                             TRY(time_cfg(c));
                         }
-                // single-frame steps: the latency variants of the direct kernel (deep prefetch ring).  For a layer of the LDS
-                // family they walk K in that family's order on its weights (ct), so the family rule above still holds bit for bit.
+                // A layer of the LDS family may also run on the direct kernel walking K in that family's order on its weights (ct):
+                // bit-identical, so the family rule above still holds.  Offered where the direct kernel has a chance: stride 2.
+                if (lds_ok && !want_fuse && op.w_lds[0] && op.cfg.stride == 2 && !op.cfg.cin16)
+                    for (int mt = 1; mt <= 4; mt *= 2)
+                        for (int nt = 1; nt <= 4; nt *= 2) {
+                            if (op.cout_pad % (16 * nt) != 0) continue;
+                            ConvCfg c = op.cfg;
+                            c.mt = mt; c.nt = nt; c.lds = false; c.ipw = 1; c.deep = false; c.ct = true;
+                            TRY(time_cfg(c));
+                        }
+                // single-frame steps: the latency variants of the direct kernel (deep prefetch ring), same rule.
                 static const bool no_deep = [] { const char *v = getenv("IRMV_NO_DEEP"); return v && v[0] == '1'; }();
                 if (counts[pass] == 1 && !want_fuse && !no_deep && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1 && (!lds_ok || op.w_lds[0])) {
                     const int tiles[4][2] = {{1, 1}, {2, 1}, {1, 2}, {1, 4}};

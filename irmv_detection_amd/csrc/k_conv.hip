@@ -250,7 +250,17 @@ bool launch_conv(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
         if (c.ks == 1 && c.stride == 1 && c.act == 1 && !c.out_f32 && !c.ct) return launch_deep<1, 1, 1, false, false>(c.mt, c.nt, a, s);
         return false;
     }
-    if (c.ct) return false;
+    if (c.ct) {   // chunk-major order on the standard prefetch ring: stride-2 3x3 layers of the LDS family
+        if (!(c.ks == 3 && c.stride == 2 && c.act == 1 && !c.out_f32 && !c.cin16)) return false;
+#define IRMV_CT(MT_, NT_)                                                        \
+        if (c.mt == MT_ && c.nt == NT_) {                                        \
+            launch_inst<3, 2, MT_, NT_, false, 1, false, true, false>(a, s);     \
+            return true;                                                         \
+        }
+        IRMV_CT(1, 1) IRMV_CT(2, 1) IRMV_CT(4, 1) IRMV_CT(1, 2) IRMV_CT(2, 2) IRMV_CT(4, 2) IRMV_CT(1, 4) IRMV_CT(2, 4) IRMV_CT(4, 4)
+#undef IRMV_CT
+        return false;
+    }
 #define IRMV_CASE(KS_, ST_, C16_, ACT_, F32_)                                                             \
     if (c.ks == KS_ && c.stride == ST_ && c.cin16 == C16_ && c.act == ACT_ && c.out_f32 == F32_)          \
         return launch_tile<KS_, ST_, C16_, ACT_, F32_>(c.mt, c.nt, a, s);
@@ -293,7 +303,12 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 // write-late), so HBM/L2 latency hides under the matrix work.
 // K order is (chunk, tap); zero padding = zeroed halo pixels.
 // ---------------------------------------------------------------------------
-constexpr int kPixStride = 96;  // bytes per staged pixel (32 ch fp16 + pad)
+// Bytes per staged pixel (32 ch fp16 = 64 B + pad), chosen so that the ds_read_b128 of a 16-lane group hit 16 distinct
+// 16-byte slots: stride 1 -> consecutive lanes are consecutive pixels, 96 B (24 dwords: period 8 over the 64 banks, the two
+// channel quarters of a group interleave); stride 2 -> consecutive lanes are two pixels apart, and 2 x 96 B = 48 dwords
+// folds lanes r and r + 4 onto the same banks (measured: 29-39 % of the stride-2 kernels' LDS cycles were bank conflicts,
+// profiles/r02_mfma.json of the round-1 layout), whereas 2 x 80 B = 40 dwords has period 8 again.
+constexpr int pix_stride(int stride) { return stride == 2 ? 80 : 96; }
 
 // hipFuncSetAttribute is per device: remember, per kernel, on which devices it has been applied
 static bool dev_flag_test_and_set(unsigned long long &mask)
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             const int oy = y0 + ly, ox = x0 + lx;
             mv[mt] = oy < a.Hout && ox < a.Wout;
             mloc[mt] = mv[mt] ? oy * a.Wout + ox : 0;
-            poff[mt] = ((ly * STRIDE) * PW + lx * STRIDE) * kPixStride + g * 16;
+            poff[mt] = ((ly * STRIDE) * PW + lx * STRIDE) * pix_stride(STRIDE) + g * 16;
         }
     } else {
         constexpr int TPX = 64 * MT;
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             mv[mt] = m < m1;
             mloc[mt] = mv[mt] ? m : m0;
             const int oy = mloc[mt] / a.Wout, ox = mloc[mt] - oy * a.Wout;
-            poff[mt] = (((oy - y0) * STRIDE) * PW + ox * STRIDE) * kPixStride + g * 16;
+            poff[mt] = (((oy - y0) * STRIDE) * PW + ox * STRIDE) * pix_stride(STRIDE) + g * 16;
         }
     }
     unsigned char *s_patch = smem;
@@ -391,17 +406,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         const int iy = iy_base + pr, ix = ix_base + pc;
         val_p[i] = use_p[i] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
         src_p[i] = a.s0.p + ((size_t)(img * a.Hin + (val_p[i] ? iy : 0)) * a.Win + (val_p[i] ? ix : 0)) * a.s0.ld + q * 8;
-        dst_p[i] = pix * kPixStride + q * 16;
+        dst_p[i] = pix * pix_stride(STRIDE) + q * 16;
     }
     const half8 *wsrc = reinterpret_cast<const half8 *>(wl) + (size_t)nblk * chunks * (9 * NT * 64);
 
-    // fused trailing 1x1 (N2 > 0): its A fragments stay in registers for the whole workgroup
-    half8 W2[N2 > 0 ? N2 : 1][2];
-    if constexpr (N2 > 0) {
-        const half8 *w2 = reinterpret_cast<const half8 *>(a.w2) + lane;
-#pragma unroll
-        for (int t2 = 0; t2 < N2; t2++) { W2[t2][0] = w2[(t2 * 2 + 0) * 64]; W2[t2][1] = w2[(t2 * 2 + 1) * 64]; }
-    }
+    // fused trailing 1x1 (N2 > 0): its A fragments (1 KiB each, L1-resident) are fetched where they are used, in the
+    // epilogue -- held across the main loop they cost 8 VGPRs per 16 output channels and pushed the N2 = 4 tiles off the
+    // large register tiles
+    const half8 *w2 = reinterpret_cast<const half8 *>(a.w2) + lane;
 
     half8 rp[PMAX], rw[WPT];
     const size_t img_stride = (size_t)a.Hin * a.Win * a.s0.ld;
@@ -472,9 +484,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                         // stand-alone 1x1 kernel reading this tensor back from memory.
 #pragma unroll
                         for (int t2 = 0; t2 < N2; t2++) {
+                            const half8 W20 = w2[(t2 * 2 + 0) * 64], W21 = w2[(t2 * 2 + 1) * 64];
                             f32x4 c2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][0], ov[0], c2, 0, 0, 0);
-                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][1], ov[1], c2, 0, 0, 0);
+                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W20, ov[0], c2, 0, 0, 0);
+                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W21, ov[1], c2, 0, 0, 0);
                             const int co = t2 * 16 + g * 4;
                             *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) =
                                 (f32x4){c2[0] + a.bias2[co], c2[1] + a.bias2[co + 1], c2[2] + a.bias2[co + 2], c2[3] + a.bias2[co + 3]};
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int kh = tap / 3, kw = tap - kh * 3;
-            const int toff = (kh * PW + kw) * kPixStride;
+            const int toff = (kh * PW + kw) * pix_stride(STRIDE);
             half8 A[NT], B[MT];
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) A[nt] = s_w[(tap * NT + nt) * 64 + lane];
@@ -544,7 +557,6 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt)
     if (a.Cin % 32 != 0 || a.s1.C != 0 || a.s0.shift != 0) return g;
     if (!((nt == 1) || ((nt == 2 || nt == 4) && a.pair))) return g;
     if (a.cout_pad % (16 * nt) != 0) return g;
-    if (stride == 2 && a.Hout * a.Wout > 400) return g;        // large stride-2 layers: the direct kernel measured as fast or faster
     int pr, pw;
     const int l2 = a.Wout % 16 == 0 ? 4 : (a.Wout % 8 == 0 ? 3 : (a.Wout % 4 == 0 ? 2 : -1));
     const int rh = l2 >= 0 ? 4 * mt * (16 >> l2) : 0;
@@ -564,7 +576,7 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt)
         pw = a.Win + 2;
     }
     if ((size_t)pr * pw * 4 > (size_t)lds_pmax(stride, mt, g.tile2d) * 256) return g;   // staging plan: pieces per thread
-    g.patch_bytes = pr * pw * kPixStride;
+    g.patch_bytes = pr * pw * pix_stride(stride);
     const size_t bytes = (size_t)g.patch_bytes + (size_t)9 * nt * 1024;
     if (bytes > 80 * 1024) return g;                            // two or more workgroups per CU
     g.bytes = bytes;

@@ -25,6 +25,7 @@ smoke)   run smoke 300 python3 __graft_entry__.py smoke ;;
 layers)  SLOTS=64 run layers64 300 python3 scripts/prof_layers.py
          SLOTS=1 TOP=70 run layers1 200 python3 scripts/prof_layers.py ;;
 bench)   run bench 600 python3 bench.py ;;
+benchhost) for g in 16 32 64; do IRMV_BENCH_SKIP=latency run benchhost_$g 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --host-group $g; done ;;
 benchq)  run benchq 400 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline ;;
 stats)   export IRMV_TUNE_CACHE=$O/tune_cache.txt
          cd /tmp; export TMPDIR=/tmp
@@ -64,6 +65,9 @@ for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:40]:
 PY
          cat $O/trace1_summary.txt | head -50 ;;
 hostprobe) run host_probe 500 python3 scripts/host_probe.py ;;
+hostprobe2) run host_probe_plain 300 python3 scripts/host_probe.py
+         PROBE_TORCH=1 run host_probe_torch 300 python3 scripts/host_probe.py
+         cp profiles/r01_tune_cache.txt $O/tc_probe.txt; IRMV_TUNE_CACHE=$O/tc_probe.txt run host_probe_cache 300 python3 scripts/host_probe.py ;;
 crashprobe) cd /tmp; export TMPDIR=/tmp
          for v in inline nozc default; do
            case $v in default) E="";; inline) E="IRMV_INLINE_COPIES=1";; nozc) E="IRMV_ZERO_COPY_RESULTS=0";; esac
