@@ -452,6 +452,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     // epilogue of one image (bias, SiLU, shortcut, fp16, NHWC store); clears the accumulators for the next one
     const int nt0 = nblk * NT;
     auto store_tile = [&](int im) {
+        // A fragments of the fused 1x1: loaded by EVERY lane (an MFMA reads its A rows from all 64 lanes, whatever the
+        // pixel mask of the B side says), live only for the epilogue
+        half8 W2[N2 > 0 ? N2 : 1][2];
+        if constexpr (N2 > 0) {
+#pragma unroll
+            for (int t2 = 0; t2 < N2; t2++) { W2[t2][0] = w2[(t2 * 2 + 0) * 64]; W2[t2][1] = w2[(t2 * 2 + 1) * 64]; }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             if (mv[mt]) {
@@ -484,10 +491,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                         // stand-alone 1x1 kernel reading this tensor back from memory.
 #pragma unroll
                         for (int t2 = 0; t2 < N2; t2++) {
-                            const half8 W20 = w2[(t2 * 2 + 0) * 64], W21 = w2[(t2 * 2 + 1) * 64];
                             f32x4 c2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W20, ov[0], c2, 0, 0, 0);
-                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W21, ov[1], c2, 0, 0, 0);
+                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][0], ov[0], c2, 0, 0, 0);
+                            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][1], ov[1], c2, 0, 0, 0);
                             const int co = t2 * 16 + g * 4;
                             *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) =
                                 (f32x4){c2[0] + a.bias2[co], c2[1] + a.bias2[co + 1], c2[2] + a.bias2[co + 2], c2[3] + a.bias2[co + 3]};

@@ -8,10 +8,14 @@ def internal_name(sym):
          re.search(r"conv3x3_lds_kernelILi(\d)ELi(\d)ELi(\d)ELb([01])ELi(\d)E", sym))
     if m:   # images-per-workgroup is a launch argument, not part of the symbol: the "_iN" suffix of the bench name is dropped
         return f"conv3x3s{m.group(1)}_lds_mt{m.group(2)}_nt{m.group(3)}" + ("+1x1" if m.group(5) != "0" else "")
-    m = re.search(r"conv_mfma_kernel<(\d), (\d), (\d), (\d), (true|false), (\d), (true|false)>", sym)
+    m = re.search(r"conv_mfma_kernel<(\d), (\d), (\d), (\d), (true|false), (\d), (true|false)(?:, (true|false), (true|false))?>", sym)
     if m:
-        ks, st, mt, nt, c16, act, f32 = m.groups()
-        return f"conv{ks}x{ks}s{st}_mt{mt}_nt{nt}" + ("_c16" if c16 == "true" else "") + ("_f32" if f32 == "true" else "")
+        ks, st, mt, nt, c16, act, f32, ct, deep = m.groups()
+        return (f"conv{ks}x{ks}s{st}_mt{mt}_nt{nt}" + ("_c16" if c16 == "true" else "") + ("_f32" if f32 == "true" else "") +
+                ("_deep" if deep == "true" else "") + ("_ct" if ct == "true" else ""))
+    m = re.search(r"c2f32_kernel<(\d), (\d), (true|false)>", sym)
+    if m:
+        return {"0": "c2f32_ab", "1": "c2f32_a", "2": "c2f32_b"}[m.group(1)]
     for k, v in (("front_kernel", "front_fused"), ("c2f2_kernel", "c2f2_fused"), ("light_extract_kernel", "light_extract"), ("preprocess_kernel", "preprocess"), ("conv0_kernel", "conv0_mfma"), ("sppf_pool", "sppf_pool"), ("decode_kernel", "decode"), ("nms_pnp_kernel", "nms_pnp")):
         if k in sym:
             return v

@@ -27,6 +27,21 @@ layers)  SLOTS=64 run layers64 300 python3 scripts/prof_layers.py
 bench)   run bench 600 python3 bench.py ;;
 benchhost) for g in 16 32 64; do IRMV_BENCH_SKIP=latency run benchhost_$g 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --host-group $g; done ;;
 benchq)  run benchq 400 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline ;;
+profiles) # everything the round's profiles/ are made of, one tile table for all of it (first use tunes and writes it)
+         export IRMV_TUNE_CACHE=$O/tune_cache.txt; rm -f $IRMV_TUNE_CACHE
+         run bench 700 python3 bench.py
+         grep '^{' $O/bench.log | tail -1 > $O/bench.json
+         cd /tmp; export TMPDIR=/tmp
+         IRMV_BENCH_SKIP=latency,h2d run prof_stats 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline
+         IRMV_STREAMS=1 run pmc_f 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_w 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_a 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_b 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         cd $R
+         python3 scripts/collect_traffic.py $O/pmc_f/*/*_counter_collection.csv $O/pmc_w/*/*_counter_collection.csv $O/traffic.json
+         python3 scripts/collect_mfma.py $O/mfma.json $O/pmc_a/*/*_counter_collection.csv $O/pmc_b/*/*_counter_collection.csv
+         cp $O/prof_stats/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+         unset IRMV_TUNE_CACHE ;;
 stats)   export IRMV_TUNE_CACHE=$O/tune_cache.txt
          cd /tmp; export TMPDIR=/tmp
          IRMV_BENCH_SKIP=latency,h2d run prof_stats 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline
@@ -78,6 +93,7 @@ crashprobe) cd /tmp; export TMPDIR=/tmp
            if [ $rc -ge 124 ]; then echo "crashprobe $v died: stopping the chain" | tee -a $O/stages.log; exit $rc; fi
          done
          cd $R ;;
+tunev)   SLOTS=1 run tune_verbose 300 python3 scripts/tune_verbose.py ;;
 stamps)  TAG=stamps IRMV_NMS_STAMPS=1 run nms_stamps 200 python3 scripts/lat_probe.py ;;
 headerr) run head_error 400 python3 scripts/head_error.py ;;
 lat)     TAG=linear run lat_linear 200 python3 scripts/lat_probe.py
