@@ -1121,7 +1121,13 @@ static int autotune_convs(irmv_engine *e)
             }
             if (!have_hit)
             {
+                // diagnostic: IRMV_FORCE_S2=lds|ct|deep restricts the stride-2 layers of the LDS family to one implementation
+                static const char *force_s2 = getenv("IRMV_FORCE_S2");
                 auto time_cfg = [&](const ConvCfg &c) -> int {
+                    if (force_s2 && lds_ok && op.cfg.stride == 2) {
+                        const char *kind = c.lds ? "lds" : (c.deep ? "deep" : "ct");
+                        if (strcmp(kind, force_s2) != 0) return IRMV_OK;
+                    }
                     bool ok = true;
                     for (int i = 0; i < 2 && ok; i++) ok = run_conv(op, c, a, counts[pass], e->stream);
                     if (!ok) return IRMV_OK;

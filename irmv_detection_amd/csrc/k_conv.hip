@@ -461,7 +461,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            if (mv[mt]) {
+            // N2 > 0: the fused 1x1's MFMAs must run with every lane (their A rows live in all 64 lanes; inside a divergent
+            // region the compiler is also free to sink the A-fragment loads behind the mask): masked pixels run the
+            // epilogue arithmetic on whatever their accumulators hold and only their STORES are skipped.
+            if (N2 > 0 || mv[mt]) {
                 const size_t m = (size_t)im * HWo + mloc[mt];
                 if constexpr (NT % 2 == 0) {   // pair-packed (host guarantees): 8 contiguous channels per lane
                     half8 ov[NT / 2];
@@ -495,8 +498,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                             c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][0], ov[0], c2, 0, 0, 0);
                             c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][1], ov[1], c2, 0, 0, 0);
                             const int co = t2 * 16 + g * 4;
-                            *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) =
-                                (f32x4){c2[0] + a.bias2[co], c2[1] + a.bias2[co + 1], c2[2] + a.bias2[co + 2], c2[3] + a.bias2[co + 3]};
+                            if (mv[mt])
+                                *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) =
+                                    (f32x4){c2[0] + a.bias2[co], c2[1] + a.bias2[co + 1], c2[2] + a.bias2[co + 2], c2[3] + a.bias2[co + 3]};
                         }
                     }
                 } else {

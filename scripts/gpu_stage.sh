@@ -93,6 +93,7 @@ crashprobe) cd /tmp; export TMPDIR=/tmp
            if [ $rc -ge 124 ]; then echo "crashprobe $v died: stopping the chain" | tee -a $O/stages.log; exit $rc; fi
          done
          cd $R ;;
+s2probe) NET=416 run s2_probe 300 python3 scripts/s2_probe.py ;;
 tunev)   SLOTS=1 run tune_verbose 300 python3 scripts/tune_verbose.py ;;
 stamps)  TAG=stamps IRMV_NMS_STAMPS=1 run nms_stamps 200 python3 scripts/lat_probe.py ;;
 headerr) run head_error 400 python3 scripts/head_error.py ;;
