@@ -80,41 +80,43 @@ def parse_args():
 
 def cpu_baseline(blob: bytes, frames_u8, n_frames: int, K, D):
     """Oracle pipeline (preprocess -> net -> decode+NMS -> PnP) on the host cores."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")     # before libgomp comes up with liboracle.so
     from oracle import oracle
     oracle.build()
     net = oracle.Net(blob)
-    # the box reports every host CPU; a one-GPU share is 16 of them
-    threads = int(os.environ.get("OMP_NUM_THREADS", min(len(os.sched_getaffinity(0)), 16)))
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    # one untimed pass to page everything in
-    x = oracle.preprocess(frames_u8[0], 640)
-    net.forward(x)
-    t0 = time.perf_counter()
-    done = 0
-    for i in range(n_frames):
-        f = frames_u8[i % len(frames_u8)]
+    # The box reports every host CPU, a one-GPU share is 16 of them, and the container's quota may be smaller still: an
+    # OpenMP team larger than the quota collapses (spinning barriers; measured 0.1 frames/s with 16 threads where one
+    # thread does 3.4).  So: passive waiting, and the team size is the best of {16, 8, 4, 2, 1} on one probe frame.
+    cap = int(os.environ.get("OMP_NUM_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+
+    def one_frame(f):
         x = oracle.preprocess(f, 640)
         head = net.forward(x)
         d = oracle.decode_nms(head, 640, net.nc, net.nk)
         kp = d["kpts"].reshape(-1, 4, 2) * np.array([f.shape[1] / 640.0, f.shape[0] / 640.0], np.float32)
         for j in range(d["num_dets"]):
             oracle.solve_pnp_ippe(K, D, kp[j], 0)
+
+    one_frame(frames_u8[0])                       # pages everything in
+    best, threads, one = None, 1, None
+    for t in [c for c in (16, 8, 4, 2, 1) if c <= cap]:
+        oracle.lib().orc_set_threads(t)
+        t1 = time.perf_counter()
+        one_frame(frames_u8[0])
+        dt1 = time.perf_counter() - t1
+        if t == 1:
+            one = round(1.0 / dt1, 3)
+        if best is None or dt1 < best:
+            best, threads = dt1, t
+    oracle.lib().orc_set_threads(threads)
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(n_frames):
+        one_frame(frames_u8[i % len(frames_u8)])
         done += 1
-        if time.perf_counter() - t0 > 30.0:
+        if time.perf_counter() - t0 > 20.0:
             break
     dt = time.perf_counter() - t0
-    # the same pipeline on ONE thread (SURVEY 8d asks for both numbers), two frames
-    one = None
-    try:
-        oracle.lib().orc_set_threads(1)
-        t1 = time.perf_counter()
-        for i in range(2):
-            f = frames_u8[i % len(frames_u8)]
-            d = oracle.decode_nms(net.forward(oracle.preprocess(f, 640)), 640, net.nc, net.nk)
-        one = round(2 / (time.perf_counter() - t1), 3)
-        oracle.lib().orc_set_threads(threads)
-    except AttributeError:
-        pass
     return dict(value=round(done / dt, 3), unit="frames/s", cores=threads, kind="port", value_1_thread=one,
                 sample=f"{done} synthetic 1280x1024 frames through the CPU oracle (fp32, OpenMP x{threads}), {dt:.1f} s")
 

@@ -1101,7 +1101,7 @@ static int autotune_convs(irmv_engine *e)
                     const bool pow2 = (h.mt == 1 || h.mt == 2 || h.mt == 4) && (h.nt == 1 || h.nt == 2 || h.nt == 4) && (h.ipw == 1 || h.ipw == 2 || h.ipw == 4);
                     // family: LDS-staged, or (single-frame steps only) its chunk-major stand-in on the direct kernel; never both flags
                     const bool fam_ok = lds_ok ? ((h.lds && !h.ct && !h.deep) || (!h.lds && h.ct && !want_fuse && (!h.deep || counts[pass] == 1)))
-                                               : (!h.lds && !h.ct && (!h.deep || counts[pass] == 1));
+                                               : (!h.lds && !h.ct && (!h.deep || counts[pass] == 1 || op.cfg.ks == 1));
                     bool ok = pow2 && op.cout_pad % (16 * h.nt) == 0 && h.ipw <= counts[pass] && fam_ok && (!want_fuse || h.nt == 4);
                     if (ok && h.lds) {
                         const int li = h.nt == 4 ? 2 : (h.nt == 2 ? 1 : 0);
@@ -1171,7 +1171,8 @@ static int autotune_convs(irmv_engine *e)
                         }
                 // single-frame steps: the latency variants of the direct kernel (deep prefetch ring), same rule.
                 static const bool no_deep = [] { const char *v = getenv("IRMV_NO_DEEP"); return v && v[0] == '1'; }();
-                if (counts[pass] == 1 && !want_fuse && !no_deep && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1 && (!lds_ok || op.w_lds[0])) {
+                // Batched steps: offered to the 1x1 layers only (4..16 k-steps: the ring then holds the wave's whole K range).
+                if ((counts[pass] == 1 || op.cfg.ks == 1) && !want_fuse && !no_deep && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1 && (!lds_ok || op.w_lds[0])) {
                     const int tiles[4][2] = {{1, 1}, {2, 1}, {1, 2}, {1, 4}};
                     for (auto &t : tiles) {
                         if (op.cout_pad % (16 * t[1]) != 0) continue;
