@@ -13,6 +13,8 @@
 // bit-identical to the unfused layers (tests/test_gpu_engine.py::test_fused_kernels_are_bitwise_identical).
 #include "irmv_common.hpp"
 
+#include <mutex>
+
 namespace irmv {
 
 namespace {
@@ -491,6 +493,8 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
     }
 }
 
+static std::mutex g_c2f_attr_mu;
+
 size_t c2f32_lds_bytes(int mode) { return (size_t)(R1N + R2N + (mode == 1 ? 0 : R3N) + (mode == 0 ? R3N : 0)) * PS; }
 
 bool launch_c2f32(int mode, bool shortcut, const C2f32Args &a, int batch, hipStream_t s)
@@ -502,8 +506,13 @@ bool launch_c2f32(int mode, bool shortcut, const C2f32Args &a, int batch, hipStr
     if (mode == MODE_ && (MODE_ == 2 || ks1 == KS_) && shortcut == SC_) {                                          \
         static unsigned long long attr_done = 0;                                                                   \
         int dev = 0; (void)hipGetDevice(&dev);                                                                     \
-        if (!(__atomic_fetch_or(&attr_done, 1ull << (dev & 63), __ATOMIC_RELAXED) & (1ull << (dev & 63))))         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(c2f32_kernel<MODE_, KS_, SC_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+        {   /* per device, once, and nobody launches before the limit is raised */                                 \
+            std::lock_guard<std::mutex> lk(g_c2f_attr_mu);                                                         \
+            if (!(attr_done & (1ull << (dev & 63)))) {                                                             \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(c2f32_kernel<MODE_, KS_, SC_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+                attr_done |= 1ull << (dev & 63);                                                                   \
+            }                                                                                                      \
+        }                                                                                                          \
         hipLaunchKernelGGL((c2f32_kernel<MODE_, KS_, SC_>), grid, block, lds, s, a);                               \
         return true;                                                                                               \
     }

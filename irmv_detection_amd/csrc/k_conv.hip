@@ -16,6 +16,7 @@
 #include "irmv_common.hpp"
 
 #include <cstdio>
+#include <mutex>
 
 namespace irmv {
 
@@ -310,15 +311,20 @@ const char *conv_cfg_name(const ConvCfg &c, char *buf, int n)
 // profiles/r02_mfma.json of the round-1 layout), whereas 2 x 80 B = 40 dwords has period 8 again.
 constexpr int pix_stride(int stride) { return stride == 2 ? 80 : 96; }
 
-// hipFuncSetAttribute is per device: remember, per kernel, on which devices it has been applied
-static bool dev_flag_test_and_set(unsigned long long &mask)
+// hipFuncSetAttribute is per device: remember, per kernel, on which devices it has been applied.  Engines may be created
+// and run from several threads (one per GPU): the check, the attribute call and the flag update are one critical section,
+// so no thread launches before the limit is raised.
+static std::mutex g_attr_mu;
+template <class F>
+static void once_per_device(unsigned long long &mask, F set_attribute)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
-    const bool was = (mask & bit) != 0;
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (mask & bit) return;
+    set_attribute();
     mask |= bit;
-    return was;
 }
 
 // 16-byte patch pieces a thread stages per chunk (registers are reserved for all of them): a stride-1 2-D block is at
@@ -604,8 +610,9 @@ template <int STRIDE, int MT, int NT, bool TILE2D, int N2>
 static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int ipw, const LdsGeom &g, hipStream_t s)
 {
     static unsigned long long attr_done = 0;   // per instantiation: devices whose dynamic-LDS limit has been raised
-    if (!dev_flag_test_and_set(attr_done))
+    once_per_device(attr_done, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
     const int groups = (batch + ipw - 1) / ipw;
     hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
                        wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch);
@@ -787,8 +794,9 @@ void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s
     if (cw) {
         const size_t lds = (size_t)4 * H * W * cw * 2;
         static unsigned long long attr_done = 0;
-        if (!dev_flag_test_and_set(attr_done))
+        once_per_device(attr_done, [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sppf_pool_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
         hipLaunchKernelGGL(sppf_pool_lds_kernel, dim3(batch * (C / cw)), dim3(256), lds, s, buf, H, W, C, cw);
         return;
     }

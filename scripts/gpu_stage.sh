@@ -99,11 +99,6 @@ stamps)  TAG=stamps IRMV_NMS_STAMPS=1 run nms_stamps 200 python3 scripts/lat_pro
 headerr) run head_error 400 python3 scripts/head_error.py ;;
 lat)     TAG=linear run lat_linear 200 python3 scripts/lat_probe.py
          TAG=fork_head IRMV_FORK_HEAD=1 run lat_fork 200 python3 scripts/lat_probe.py ;;
-repro_old) # diagnosis only: the round-1 counter scheme (memset node at the head of the step, no self-reset); the kernel's clamp keeps
-         # the walk inside the list, n_candidates reports the raw counter
-         cd /tmp; export TMPDIR=/tmp
-         IRMV_COUNTS_MEMSET=1 IRMV_REPRO_REPORT=1 run repro_old 300 rocprofv3 --kernel-trace --output-format csv -d $O/repro_old -- python3 $R/scripts/repro_two_engines.py
-         cd $R ;;
 repro)   # the round-1 fault sequence, ONCE, under the profiler that exposed it, with every allocation range logged
          cd /tmp; export TMPDIR=/tmp
          IRMV_LOG_ALLOC=1 run repro_prof 300 rocprofv3 --kernel-trace --output-format csv -d $O/repro_prof -- python3 $R/scripts/repro_two_engines.py
