@@ -4,15 +4,16 @@
 // (src/yolo_engine.cpp:179-200) and the first two convolutions of the TensorRT plan
 // (src/yolo_engine.cpp:105).  Run as separate kernels these three steps move
 // 3.93 + 3.28 | 3.28 + 3.28 | 3.28 + 1.64 MB per 1280x1024 frame -- they are the
-// bandwidth-bound high-resolution part of the network.  Fused, a workgroup owns an
-// 8 x 16 tile of model.1's output and keeps everything in between in LDS:
+// bandwidth-bound high-resolution part of the network.  Fused, a workgroup owns a
+// 4 x 16 tile of model.1's output and keeps everything in between in LDS:
 //
-//   A  source region of the tile (with the halo of two stride-2 3x3 convs: 35 x 67
-//      net-input pixels) -> LDS with 16-byte loads; bilinear resample, /255, fp16
-//      NHWC4 into LDS (same fixed-point arithmetic as preprocess_kernel)
-//   B  model.0.conv (3 -> 16, s2, SiLU) on MFMA from LDS -> 17 x 33 fp16 pixels in LDS
+//   A  source region of the tile (with the halo of two stride-2 3x3 convs: 19 x 67
+//      net-input pixels; ~33 rows x 140 source pixels for 1280 x 1024 -> 640) -> LDS as
+//      4-byte pixels; bilinear resample, /255, fp16 NHWC4 into LDS (same fixed-point
+//      arithmetic as preprocess_kernel)
+//   B  model.0.conv (3 -> 16, s2, SiLU) on MFMA from LDS -> 9 x 33 fp16 pixels in LDS
 //      (zero outside the image: they are model.1's padding)
-//   C  model.1.conv (16 -> 32, s2, SiLU) on MFMA from LDS -> 8 x 16 x 32 fp16 to HBM
+//   C  model.1.conv (16 -> 32, s2, SiLU) on MFMA from LDS -> 4 x 16 x 32 fp16 to HBM
 //
 // so a frame costs 3.93 MB read + 1.64 MB written.  Every value is rounded to fp16
 // exactly where the unfused kernels store their tensors and every MFMA sees the same
@@ -90,16 +91,40 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs a)
         const size_t row_bytes = (size_t)a.sw * 3;
         const uint8_t *src = a.src + (size_t)b * a.src_slot_bytes + (size_t)sy_min * row_bytes + (size_t)x0 * 3;
         const int gpr = pitch >> 2, total = (sy_max - sy_min + 1) * gpr;
-        for (int i = tid; i < total; i += 256) {
-            const int row = i / gpr, gq = i - row * gpr;
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)row * row_bytes + (size_t)gq * 12);
-            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-            uint4 o;
-            o.x = d0 & 0xffffffu;
-            o.y = (d0 >> 24) | ((d1 & 0xffffu) << 8);
-            o.z = (d1 >> 16) | ((d2 & 0xffu) << 16);
-            o.w = d2 >> 8;
-            *reinterpret_cast<uint4 *>(s_px + row * pitch + gq * 4) = o;
+        // All loads of a pass are issued before its first LDS store: a thread owns ~5 groups of the reference geometry
+        // (33 rows x 35 groups / 256 threads), and one group per loop trip meant ~5 exposed memory round trips per
+        // workgroup -- of a ~10 us workgroup lifetime.  CH = 6 groups per pass: one round trip for 1280 x 1024 -> 640.
+        constexpr int CH = 6;
+        const float inv_gpr = 1.0f / (float)gpr;
+        for (int i0 = 0; i0 < total; i0 += 256 * CH) {
+            uint32_t d0[CH], d1[CH], d2[CH];
+            int dst[CH];
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const int i = i0 + c * 256 + tid;
+                dst[c] = -1;
+                d0[c] = d1[c] = d2[c] = 0u;
+                if (i < total) {
+                    int row = (int)((float)i * inv_gpr);          // i < 2^15: one correction step makes the quotient exact
+                    row -= (row * gpr > i) ? 1 : 0;
+                    row += ((row + 1) * gpr <= i) ? 1 : 0;
+                    const int gq = i - row * gpr;
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)row * row_bytes + (size_t)gq * 12);
+                    d0[c] = q[0]; d1[c] = q[1]; d2[c] = q[2];
+                    dst[c] = row * pitch + gq * 4;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                if (dst[c] >= 0) {
+                    uint4 o;
+                    o.x = d0[c] & 0xffffffu;
+                    o.y = (d0[c] >> 24) | ((d1[c] & 0xffffu) << 8);
+                    o.z = (d1[c] >> 16) | ((d2[c] & 0xffu) << 16);
+                    o.w = d2[c] >> 8;
+                    *reinterpret_cast<uint4 *>(s_px + dst[c]) = o;
+                }
+            }
         }
     }
     __syncthreads();
@@ -108,11 +133,14 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs a)
     {
         const half_t padv = (half_t)(114.0f / 255.0f);
         const float inv255 = 1.0f / 255.0f;   // (half)(q * inv255) == (half)(q / 255.0f) for every q in 0..255 (tests/test_oracle_preprocess.py)
-#pragma unroll 2
-        for (int p = tid; p < INH * INP; p += 256) {
-            const int ly = p / INP, lx = p - ly * INP;
+        if (tid < INH) s_in[tid * INP + INW] = (half4){0, 0, 0, 0};   // the extra column of every row stays zero
+        // 19 x 67 = 1273 pixels = five trips of 256 lanes (walking the padded 19 x 68 grid would need a sixth for 12 pixels)
+#pragma unroll 5
+        for (int pp = tid; pp < INH * INW; pp += 256) {
+            const int ly = pp / INW, lx = pp - ly * INW;
+            const int p = ly * INP + lx;
             half4 o = (half4){0, 0, 0, 0};
-            if (lx < INW && (unsigned)(gy0 + ly) < (unsigned)net && (unsigned)(gx0 + lx) < (unsigned)net) {
+            if ( (unsigned)(gy0 + ly) < (unsigned)net && (unsigned)(gx0 + lx) < (unsigned)net) {
                 const uint32_t ty = s_ty[ly], tx = s_tx[lx];
                 if (ty == 0xffffffffu || tx == 0xffffffffu) {
                     o = (half4){padv, padv, padv, (half_t)0.0f};
