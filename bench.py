@@ -267,47 +267,60 @@ def main():
                                             "pinned memory on the download stream; SURVEY 8(d) clock")
         extra["fps_pcie_inclusive_1gpu"] = round(B * hsteps / dth, 1)
     if rank == 0 and "latency" not in skip:
+        # Latency legs on an engine shaped like the reference node's: three slots = the TripleBuffer (src/irm_detector.cpp:
+        # 35-38, 68-72), a compute stream per slot.  (A second engine in the process: safe since the round-2 teardown fix.)
+        if torch is not None:
+            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=3)
+        else:
+            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=3)
+        for s3 in range(3):
+            leng.get_src_image_buffer(s3)[:] = frames_u8[s3 % len(frames_u8)]
         # single-frame latency, host frame -> host detections (the reference's detect(), PCIe inclusive)
         dbg("single-frame latency")
         for _ in range(20):
-            eng.detect(0)
+            leng.detect(0)
         lat = []
         for _ in range(100):
-            eng.detect(0)
-            lat.append(eng.get_profiling_time())
+            leng.detect(0)
+            lat.append(leng.get_profiling_time())
         extra["latency_ms_single_frame_h2d_inclusive"] = round(float(np.median(lat)), 4)
         # the captured single-frame step alone (frame already in HBM)
         for _ in range(10):
-            eng.submit(0, 1, h2d=False); eng.wait()
+            leng.submit(0, 1, h2d=False); leng.wait()
         t1 = time.perf_counter()
         for _ in range(100):
-            eng.submit(0, 1, h2d=False); eng.wait()
+            leng.submit(0, 1, h2d=False); leng.wait()
         extra["latency_ms_single_frame_hbm_resident"] = round((time.perf_counter() - t1) * 10, 4)
         # the reference's harness shape (test/yolo_test.cpp:69-103): 100 warm-ups, 30 runs x 10 iterations of
         # {memcpy of the 3.93 MB frame into the engine's slot; detect()}, per-run mean in ms
-        buf = eng.get_src_image_buffer(0)
+        buf = leng.get_src_image_buffer(0)
         img = frames_u8[0]
         for _ in range(100):
-            buf[:] = img; eng.detect(0)
+            buf[:] = img; leng.detect(0)
         runs = []
         for _ in range(30):
             t1 = time.perf_counter()
             for _ in range(10):
-                buf[:] = img; eng.detect(0)
+                buf[:] = img; leng.detect(0)
             runs.append((time.perf_counter() - t1) * 100.0)
         extra["latency_harness_ms"] = dict(avg=round(float(np.mean(runs)), 4), max=round(float(np.max(runs)), 4), min=round(float(np.min(runs)), 4),
                                            shape="reference test/yolo_test.cpp:69-103: 100 warm-ups, 30 runs x 10 x {memcpy frame -> slot; detect()}")
-        # one frame in flight at a time through three pipelined slots: slot n+1 uploads while slot n computes
-        S3 = min(3, B)
-        if S3 >= 2:
-            n_pipe = 300
-            eng.submit(0, 1, async_upload=True)
+        # BASELINE configs[1]/[2]: single 640x640-net frames, one captured step each, through the three slots with the
+        # TripleBuffer's depth in flight: slot n + d uploads / computes while slot n is collected (H2D inclusive)
+        pipe = {}
+        for depth in (1, 2):
+            for j in range(depth):
+                leng.submit(j, 1, async_upload=True)
+            n_pipe = 600
             t1 = time.perf_counter()
             for i in range(n_pipe):
-                eng.submit((i + 1) % S3, 1, async_upload=True)
-                eng.wait_slots(i % S3, 1)
-            eng.wait()
-            extra["fps_pipelined_single_frames"] = round(n_pipe / (time.perf_counter() - t1), 1)
+                leng.submit((i + depth) % 3, 1, async_upload=True)
+                leng.wait_slots(i % 3, 1)
+            leng.wait()
+            pipe[depth + 1] = round(n_pipe / (time.perf_counter() - t1), 1)
+        extra["fps_single_frames_in_flight"] = {"1": round(1e3 / extra["latency_ms_single_frame_h2d_inclusive"], 1), "2": pipe[2], "3": pipe[3],
+                                                "note": "one frame per captured step, frames from pinned host slots (H2D inclusive), three slots, a compute stream per slot"}
+        leng.close()
 
     out = None
     dbg("profile")

@@ -573,7 +573,9 @@ static int build_engine(irmv_engine *e)
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
     }
     { const char *f = getenv("IRMV_FORK_HEAD"); e->fork_head = f && f[0] == '1'; }
-    e->num_streams = c.num_streams > 0 ? c.num_streams : 2;
+    // default: two concurrently replayed sub-batches for batched engines (measured best); a stream per slot
+    // for engines of TripleBuffer size, whose single-slot steps then overlap
+    e->num_streams = c.num_streams > 0 ? c.num_streams : (c.num_slots <= 4 ? c.num_slots : 2);
     if (const char *ns = getenv("IRMV_STREAMS")) e->num_streams = atoi(ns);
     e->num_streams = std::max(1, std::min({e->num_streams, 8, c.num_slots}));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));
@@ -1556,7 +1558,9 @@ extern "C" int irmv_engine_submit(irmv_engine *e, int first, int count, uint32_t
     // separate streams: while one sub-batch sits in a launch gap or a kernel tail the other keeps the
     // CUs busy (two sub-batches measured +30 % frames/s over one stream at 32 frames).
     const int share = count > 1 ? stream_share(e, count) : count;
-    int si = 0;
+    // Single-slot steps ride the compute stream of their slot (slot mod num_streams): a single frame fills a fraction of
+    // the chip, so the steps of two slots in flight (the TripleBuffer's depth) overlap instead of queueing behind each other.
+    int si = count == 1 ? first % e->num_streams : 0;
     for (int f = first; f < first + count; f += share, si++) {
         const int c = std::min(share, first + count - f);
         hipStream_t st = si == 0 ? e->stream : e->extra_streams[si - 1];

@@ -17,13 +17,17 @@ t0 = time.perf_counter()
 for _ in range(200):
     eng.detect(0)
 t_det = (time.perf_counter() - t0) / 200
-eng.submit(0, 1, async_upload=True)
-t0 = time.perf_counter()
-n = 300
-for i in range(n):
-    eng.submit((i + 1) % 3, 1, async_upload=True)
-    eng.wait_slots(i % 3, 1)
-eng.wait()
-t_pipe = (time.perf_counter() - t0) / n
-print(f"[{os.environ.get('TAG', '')}] step (HBM resident) {t_res*1e3:.4f} ms; detect (H2D inclusive) {t_det*1e3:.4f} ms; pipelined 3 slots {t_pipe*1e3:.4f} ms/frame = {1/t_pipe:.0f} FPS", flush=True)
+res = []
+for depth in (1, 2):
+    for j in range(depth):
+        eng.submit(j, 1, async_upload=True)
+    t0 = time.perf_counter()
+    n = 300
+    for i in range(n):
+        eng.submit((i + depth) % 3, 1, async_upload=True)
+        eng.wait_slots(i % 3, 1)
+    eng.wait()
+    res.append((time.perf_counter() - t0) / n)
+print(f"[{os.environ.get('TAG', '')}] streams {eng.num_streams}; step (HBM resident) {t_res*1e3:.4f} ms; detect (H2D inclusive) {t_det*1e3:.4f} ms; pipelined 3 slots: "
+      f"2 in flight {res[0]*1e3:.4f} ms/frame = {1/res[0]:.0f} FPS, 3 in flight {res[1]*1e3:.4f} ms/frame = {1/res[1]:.0f} FPS", flush=True)
 eng.close()
