@@ -171,6 +171,9 @@ void *irmv_engine_src_device_buffer(irmv_engine *e, int slot);
 int irmv_engine_submit(irmv_engine *e, int first_slot, int count, uint32_t flags);
 /* Block until everything submitted so far is done and host-visible. */
 int irmv_engine_wait(irmv_engine *e);
+/* Block until the pinned slots [first, first+count) have been uploaded by their last submit: a producer may overwrite them
+ * from then on (the TripleBuffer's consumer can give the buffer back) while the kernels still run. */
+int irmv_engine_wait_upload(irmv_engine *e, int first_slot, int count);
 /* Block until the results of slots [first, first+count) are host-visible; other slots stay in flight. */
 int irmv_engine_wait_slots(irmv_engine *e, int first_slot, int count);
 /* Results of one slot after wait(): up to cap detections, score-descending. */

@@ -86,6 +86,7 @@ SYMBOLS = [
     ("irmv_engine_submit", C.c_int, [_P, C.c_int, C.c_int, C.c_uint32]),
     ("irmv_engine_wait", C.c_int, [_P]),
     ("irmv_engine_wait_slots", C.c_int, [_P, C.c_int, C.c_int]),
+    ("irmv_engine_wait_upload", C.c_int, [_P, C.c_int, C.c_int]),
     ("irmv_engine_set_extract_params", C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_double)]),
     ("irmv_engine_point_source", C.c_int, [_P]),
     ("irmv_engine_results", C.c_int, [_P, C.c_int, C.POINTER(Det), C.c_int, C.POINTER(C.c_int)]),

@@ -176,6 +176,7 @@ struct SlotGroup {
     hipEvent_t h2d = nullptr, done = nullptr, out = nullptr;
     hipStream_t compute = nullptr;   // compute stream of the last submit
     bool in_flight = false;          // submitted and not yet known complete
+    bool async_up = false;           // the last submit uploaded on the side stream (event h2d is valid)
 };
 
 struct irmv_engine {
@@ -1546,6 +1547,7 @@ static int submit_group(irmv_engine *e, int f, int c, uint32_t flags, hipStream_
     TRY(copy_out(e, f, c, st));
     HIP_TRY(hipEventRecord(g->out, st));
     g->in_flight = true;
+    g->async_up = async_up;
     g->compute = st;
     return IRMV_OK;
 }
@@ -1592,6 +1594,24 @@ extern "C" int irmv_engine_wait(irmv_engine *e)
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamSynchronize(e->extra_streams[i - 1]));
     for (auto &kv : e->groups) kv.second.in_flight = false;
+    return IRMV_OK;
+}
+
+// Block until the pinned slots [first, first + count) have been read by their last submit's upload: from then on a producer
+// may overwrite them (the moment the TripleBuffer's consumer can give the buffer back), while the kernels still run.
+extern "C" int irmv_engine_wait_upload(irmv_engine *e, int first, int count)
+{
+    TRY(check_range(e, first, count));
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    SlotGroup *last = nullptr;
+    for (int s = first; s < first + count; s++) {
+        SlotGroup *o = e->slot_owner[s];
+        if (!o || o == last || !o->in_flight) continue;
+        // an upload on the side stream has its own event; an inline upload is ordered in front of the kernels, so the
+        // group's completion event covers it
+        HIP_TRY(hipEventSynchronize(o->async_up ? o->h2d : o->out));
+        last = o;
+    }
     return IRMV_OK;
 }
 

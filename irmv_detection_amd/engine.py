@@ -241,6 +241,10 @@ class YoloEngine:
     def wait(self) -> None:
         capi.check(self._L.irmv_engine_wait(self._h))
 
+    def wait_upload(self, first_slot: int, count: int = 1) -> None:
+        """Block until these pinned slots have been uploaded (a producer may overwrite them; the kernels still run)."""
+        capi.check(self._L.irmv_engine_wait_upload(self._h, first_slot, count))
+
     def wait_slots(self, first_slot: int, count: int = 1) -> None:
         """Block until these slots' results are host-visible; other slots stay in flight."""
         capi.check(self._L.irmv_engine_wait_slots(self._h, first_slot, count))

@@ -37,7 +37,7 @@ struct StampedImage {   // reference include/irmv_detection/camera.hpp:27-32
 
 struct RunStats { double producer_fps, consumer_fps, lat_mean_ms, lat_p99_ms, lat_max_ms; long produced, consumed, dets; };
 
-static RunStats run(irmv_engine * eng, const std::vector<uint8_t> & frames, int n_frames, size_t frame_bytes, double fps, double seconds)
+static RunStats run(irmv_engine * eng, const std::vector<uint8_t> & frames, int n_frames, size_t frame_bytes, double fps, double seconds, bool pipelined = false)
 {
   std::array<StampedImage, 3> slots;
   for (int i = 0; i < 3; i++) { slots[i].data = irmv_engine_src_buffer(eng, i); slots[i].id = i; }
@@ -69,19 +69,47 @@ static RunStats run(irmv_engine * eng, const std::vector<uint8_t> & frames, int 
   std::vector<irmv_det> out(100);
   long last_seq = -1;
   bool order_ok = true;
+  // pipelined consumer: the slot's upload is awaited (then the TripleBuffer may hand the buffer back to the producer), its
+  // kernels run while the NEXT buffer is fetched and uploaded; results are collected one frame late
+  int pending = -1;
+  clk::time_point pending_stamp;
+  auto collect = [&](int slot, clk::time_point stamp) {
+    int n = 0;
+    if (irmv_engine_wait_slots(eng, slot, 1) != IRMV_OK || irmv_engine_results(eng, slot, out.data(), 100, &n) != IRMV_OK) {
+      std::printf("collect failed: %s\n", irmv_last_error());
+      std::exit(4);
+    }
+    lat.push_back(std::chrono::duration<double, std::milli>(clk::now() - stamp).count());
+    consumed++;
+    dets += n;
+  };
   while (true) {
     StampedImage * s = tb.get_consumer_buffer();
     if (s->seq == -2) break;
     if (s->seq <= last_seq) order_ok = false;
     last_seq = s->seq;
-    int n = 0;
-    const int rc = irmv_engine_detect(eng, s->id, out.data(), 100, &n);
-    if (rc != IRMV_OK && rc != IRMV_ERR_OVERFLOW) { std::printf("detect failed: %s\n", irmv_last_error()); std::exit(4); }
-    lat.push_back(std::chrono::duration<double, std::milli>(clk::now() - s->time_stamp).count());
-    consumed++;
-    dets += n;
+    if (!pipelined) {
+      int n = 0;
+      const int rc = irmv_engine_detect(eng, s->id, out.data(), 100, &n);
+      if (rc != IRMV_OK) { std::printf("detect failed: %s\n", irmv_last_error()); std::exit(4); }
+      lat.push_back(std::chrono::duration<double, std::milli>(clk::now() - s->time_stamp).count());
+      consumed++;
+      dets += n;
+    } else {
+      if (pending == s->id) { collect(pending, pending_stamp); pending = -1; }   // the same slot again: finish its previous frame first
+      if (irmv_engine_submit(eng, s->id, 1, IRMV_SUBMIT_H2D | IRMV_SUBMIT_ASYNC_UPLOAD) != IRMV_OK || irmv_engine_wait_upload(eng, s->id, 1) != IRMV_OK) {
+        std::printf("submit failed: %s\n", irmv_last_error());
+        std::exit(4);
+      }
+      const clk::time_point stamp = s->time_stamp;
+      const int id = s->id;
+      if (pending >= 0) collect(pending, pending_stamp);
+      pending = id;
+      pending_stamp = stamp;
+    }
     if (std::chrono::duration<double>(clk::now() - t_start).count() > seconds) stop = true;
   }
+  if (pending >= 0) collect(pending, pending_stamp);
   producer.join();
   const double T = std::chrono::duration<double>(clk::now() - t_start).count();
   std::sort(lat.begin(), lat.end());
@@ -122,6 +150,9 @@ int main(int argc, char ** argv)
   const RunStats freerun = run(eng, frames, n_frames, frame_bytes, 0.0, seconds);
   std::printf("unpaced producer_fps %.1f consumer_fps %.1f lat_ms mean %.3f p99 %.3f max %.3f produced %ld consumed %ld dets %ld\n",
               freerun.producer_fps, freerun.consumer_fps, freerun.lat_mean_ms, freerun.lat_p99_ms, freerun.lat_max_ms, freerun.produced, freerun.consumed, freerun.dets);
+  const RunStats piped = run(eng, frames, n_frames, frame_bytes, 0.0, seconds, true);
+  std::printf("unpaced_pipelined producer_fps %.1f consumer_fps %.1f lat_ms mean %.3f p99 %.3f max %.3f produced %ld consumed %ld dets %ld\n",
+              piped.producer_fps, piped.consumer_fps, piped.lat_mean_ms, piped.lat_p99_ms, piped.lat_max_ms, piped.produced, piped.consumed, piped.dets);
   irmv_engine_destroy(eng);
   const bool rate_ok = paced.consumer_fps > 0.9 * paced.producer_fps && paced.producer_fps > 0.9 * 330.0;
   const bool lat_ok = paced.lat_p99_ms < 10.0;

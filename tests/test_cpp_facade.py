@@ -99,6 +99,8 @@ def test_camera_stream_330fps_through_the_triple_buffer(tmp_path, blob):
     assert abs(float(m.group(1)) - 330) < 33 and float(m.group(2)) > 0.9 * float(m.group(1)) and float(m.group(4)) < 10.0
     m = re.search(r"unpaced producer_fps (\S+) consumer_fps (\S+)", out.stdout)
     assert float(m.group(2)) > 330        # un-paced, the consumer keeps up with far more than the camera rate
+    m = re.search(r"unpaced_pipelined producer_fps (\S+) consumer_fps (\S+)", out.stdout)
+    assert float(m.group(2)) > 330        # and with one frame's kernels running under the next frame's upload
 
 
 @pytest.mark.gpu
