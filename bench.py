@@ -238,7 +238,7 @@ def main():
                 and np.array_equal(got["kpts"], want["kpts"])):
             raise SystemExit(f"bench.py: rank {rank} slot {sl}: batched step differs from the single-slot step")
 
-    extra = {}
+    extra, late = {}, {}
     skip = os.environ.get("IRMV_BENCH_SKIP", "")
     # ---- SURVEY 8(d) clock: frames start in pinned host slots, cross PCIe inside the timed region (all ranks) ----
     if "h2d" not in skip:
@@ -263,65 +263,9 @@ def main():
         extra["value_host_inclusive"] = round(world * B * hsteps / dth, 1)
         extra["host_inclusive"] = dict(frames_per_upload_group=G, steps=hsteps,
                                        pcie_gbs_per_gpu=round(B * hsteps * sw * sh * 3 / dth / 1e9, 2),
-                                       note="pinned host slot -> HBM on the upload stream inside the timed region, results back to "
-                                            "pinned memory on the download stream; SURVEY 8(d) clock")
+                                       note="pinned host slot -> HBM on the upload stream inside the timed region, results written by the NMS "
+                                            "kernel into pinned host memory; SURVEY 8(d) clock")
         extra["fps_pcie_inclusive_1gpu"] = round(B * hsteps / dth, 1)
-    if rank == 0 and "latency" not in skip:
-        # Latency legs on an engine shaped like the reference node's: three slots = the TripleBuffer (src/irm_detector.cpp:
-        # 35-38, 68-72), a compute stream per slot.  (A second engine in the process: safe since the round-2 teardown fix.)
-        if torch is not None:
-            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=3)
-        else:
-            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=3)
-        for s3 in range(3):
-            leng.get_src_image_buffer(s3)[:] = frames_u8[s3 % len(frames_u8)]
-        # single-frame latency, host frame -> host detections (the reference's detect(), PCIe inclusive)
-        dbg("single-frame latency")
-        for _ in range(20):
-            leng.detect(0)
-        lat = []
-        for _ in range(100):
-            leng.detect(0)
-            lat.append(leng.get_profiling_time())
-        extra["latency_ms_single_frame_h2d_inclusive"] = round(float(np.median(lat)), 4)
-        # the captured single-frame step alone (frame already in HBM)
-        for _ in range(10):
-            leng.submit(0, 1, h2d=False); leng.wait()
-        t1 = time.perf_counter()
-        for _ in range(100):
-            leng.submit(0, 1, h2d=False); leng.wait()
-        extra["latency_ms_single_frame_hbm_resident"] = round((time.perf_counter() - t1) * 10, 4)
-        # the reference's harness shape (test/yolo_test.cpp:69-103): 100 warm-ups, 30 runs x 10 iterations of
-        # {memcpy of the 3.93 MB frame into the engine's slot; detect()}, per-run mean in ms
-        buf = leng.get_src_image_buffer(0)
-        img = frames_u8[0]
-        for _ in range(100):
-            buf[:] = img; leng.detect(0)
-        runs = []
-        for _ in range(30):
-            t1 = time.perf_counter()
-            for _ in range(10):
-                buf[:] = img; leng.detect(0)
-            runs.append((time.perf_counter() - t1) * 100.0)
-        extra["latency_harness_ms"] = dict(avg=round(float(np.mean(runs)), 4), max=round(float(np.max(runs)), 4), min=round(float(np.min(runs)), 4),
-                                           shape="reference test/yolo_test.cpp:69-103: 100 warm-ups, 30 runs x 10 x {memcpy frame -> slot; detect()}")
-        # BASELINE configs[1]/[2]: single 640x640-net frames, one captured step each, through the three slots with the
-        # TripleBuffer's depth in flight: slot n + d uploads / computes while slot n is collected (H2D inclusive)
-        pipe = {}
-        for depth in (1, 2):
-            for j in range(depth):
-                leng.submit(j, 1, async_upload=True)
-            n_pipe = 600
-            t1 = time.perf_counter()
-            for i in range(n_pipe):
-                leng.submit((i + depth) % 3, 1, async_upload=True)
-                leng.wait_slots(i % 3, 1)
-            leng.wait()
-            pipe[depth + 1] = round(n_pipe / (time.perf_counter() - t1), 1)
-        extra["fps_single_frames_in_flight"] = {"1": round(1e3 / extra["latency_ms_single_frame_h2d_inclusive"], 1), "2": pipe[2], "3": pipe[3],
-                                                "note": "one frame per captured step, frames from pinned host slots (H2D inclusive), three slots, a compute stream per slot"}
-        leng.close()
-
     out = None
     dbg("profile")
     if rank == 0:
@@ -408,10 +352,68 @@ def main():
             "roofline": roofline,
         }
         out.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
+    eng.close()
+    if rank == 0 and "latency" not in skip:
+        # Latency legs on an engine shaped like the reference node's: three slots = the TripleBuffer (src/irm_detector.cpp:
+        # 35-38, 68-72), a compute stream per slot.  (A second engine in the process: safe since the round-2 teardown fix.)
+        if torch is not None:
+            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=3)
+        else:
+            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=3)
+        for s3 in range(3):
+            leng.get_src_image_buffer(s3)[:] = frames_u8[s3 % len(frames_u8)]
+        # single-frame latency, host frame -> host detections (the reference's detect(), PCIe inclusive)
+        dbg("single-frame latency")
+        for _ in range(20):
+            leng.detect(0)
+        lat = []
+        for _ in range(100):
+            leng.detect(0)
+            lat.append(leng.get_profiling_time())
+        late["latency_ms_single_frame_h2d_inclusive"] = round(float(np.median(lat)), 4)
+        # the captured single-frame step alone (frame already in HBM)
+        for _ in range(10):
+            leng.submit(0, 1, h2d=False); leng.wait()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            leng.submit(0, 1, h2d=False); leng.wait()
+        late["latency_ms_single_frame_hbm_resident"] = round((time.perf_counter() - t1) * 10, 4)
+        # the reference's harness shape (test/yolo_test.cpp:69-103): 100 warm-ups, 30 runs x 10 iterations of
+        # {memcpy of the 3.93 MB frame into the engine's slot; detect()}, per-run mean in ms
+        buf = leng.get_src_image_buffer(0)
+        img = frames_u8[0]
+        for _ in range(100):
+            buf[:] = img; leng.detect(0)
+        runs = []
+        for _ in range(30):
+            t1 = time.perf_counter()
+            for _ in range(10):
+                buf[:] = img; leng.detect(0)
+            runs.append((time.perf_counter() - t1) * 100.0)
+        late["latency_harness_ms"] = dict(avg=round(float(np.mean(runs)), 4), max=round(float(np.max(runs)), 4), min=round(float(np.min(runs)), 4),
+                                           shape="reference test/yolo_test.cpp:69-103: 100 warm-ups, 30 runs x 10 x {memcpy frame -> slot; detect()}")
+        # BASELINE configs[1]/[2]: single 640x640-net frames, one captured step each, through the three slots with the
+        # TripleBuffer's depth in flight: slot n + d uploads / computes while slot n is collected (H2D inclusive)
+        pipe = {}
+        for depth in (1, 2):
+            for j in range(depth):
+                leng.submit(j, 1, async_upload=True)
+            n_pipe = 600
+            t1 = time.perf_counter()
+            for i in range(n_pipe):
+                leng.submit((i + depth) % 3, 1, async_upload=True)
+                leng.wait_slots(i % 3, 1)
+            leng.wait()
+            pipe[depth + 1] = round(n_pipe / (time.perf_counter() - t1), 1)
+        late["fps_single_frames_in_flight"] = {"1": round(1e3 / late["latency_ms_single_frame_h2d_inclusive"], 1), "2": pipe[2], "3": pipe[3],
+                                                "note": "one frame per captured step, frames from pinned host slots (H2D inclusive), three slots, a compute stream per slot"}
+        leng.close()
+
+    if out is not None:
+        out.update(late)
+        if world == 1 and not args.no_cpu_baseline:      # last: nothing GPU-side is timed while the host cores are busy
             out["cpu_baseline"] = cpu_baseline(weights.synthetic_blob(0), frames_u8, args.cpu_frames,
                                                np.array(DEFAULT_CAMERA_MATRIX), np.array(DEFAULT_DIST_COEFFS))
-    eng.close()
     D.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)

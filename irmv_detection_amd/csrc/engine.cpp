@@ -173,7 +173,7 @@ struct GraphKey {
 // out = its kernels have run and its results are host-visible (so its device frames may be overwritten too).
 struct SlotGroup {
     int first = 0, count = 0;
-    hipEvent_t h2d = nullptr, done = nullptr, out = nullptr;
+    hipEvent_t h2d = nullptr, out = nullptr;
     hipStream_t compute = nullptr;   // compute stream of the last submit
     bool in_flight = false;          // submitted and not yet known complete
     bool async_up = false;           // the last submit uploaded on the side stream (event h2d is valid)
@@ -275,7 +275,6 @@ irmv_engine::~irmv_engine()
     if (light_dets_host) (void)hipHostFree(light_dets_host);
     for (auto &kv : groups) {
         if (kv.second.h2d) (void)hipEventDestroy(kv.second.h2d);
-        if (kv.second.done) (void)hipEventDestroy(kv.second.done);
         if (kv.second.out) (void)hipEventDestroy(kv.second.out);
     }
     for (int i = 0; i < 3; i++) {
@@ -568,12 +567,14 @@ static int build_engine(irmv_engine *e)
     const int net = c.net_size, S = c.num_slots;
     HIP_TRY(hipSetDevice(c.device));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 3; i++) {
+    { const char *f = getenv("IRMV_FORK_HEAD"); e->fork_head = f && f[0] == '1'; }
+    // the capture side lanes exist only for the (off by default) forked head: HIP streams are multiplexed onto a few
+    // hardware queues, and idle streams of one engine cost another engine's streams their queue
+    for (int i = 0; i < 3 && e->fork_head; i++) {
         HIP_TRY(hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_level[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
     }
-    { const char *f = getenv("IRMV_FORK_HEAD"); e->fork_head = f && f[0] == '1'; }
     // default: two concurrently replayed sub-batches for batched engines (measured best); a stream per slot
     // for engines of TripleBuffer size, whose single-slot steps then overlap
     e->num_streams = c.num_streams > 0 ? c.num_streams : (c.num_slots <= 4 ? c.num_slots : 2);
@@ -1495,7 +1496,6 @@ static int group_of(irmv_engine *e, int first, int count, SlotGroup **out)
         SlotGroup g;
         g.first = first; g.count = count;
         HIP_TRY(hipEventCreateWithFlags(&g.h2d, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g.out, hipEventDisableTiming));
         it = e->groups.emplace(key, g).first;
     }
