@@ -1008,7 +1008,7 @@ static void tune_cache_load()
     int mt, nt, lds, ipw;
     while (f >> key >> mt >> nt >> lds >> ipw) {
         ConvCfg c{};
-        c.mt = mt; c.nt = nt; c.lds = (lds & 1) != 0; c.deep = (lds & 2) != 0; c.ct = (lds & 4) != 0; c.ipw = ipw;   // bit 0 LDS family, 1 deep prefetch, 2 chunk-major
+        c.mt = mt; c.nt = nt; c.lds = (lds & 1) != 0; c.deep = (lds & 2) != 0; c.ct = (lds & 4) != 0; c.pw = (lds & 8) != 0; c.ipw = ipw;   // bit 0 LDS family, 1 deep prefetch, 2 chunk-major, 3 pointwise kernel
         g_tune_cache[key] = c;
     }
 }
@@ -1020,12 +1020,13 @@ static void tune_cache_save()
     std::lock_guard<std::mutex> lk(g_tune_mu);
     std::ofstream f(path);
     for (auto &kv : g_tune_cache)
-        f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0)) << ' ' << kv.second.ipw << '\n';
+        f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0) | (kv.second.pw ? 8 : 0)) << ' ' << kv.second.ipw << '\n';
 }
 
 static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int count, hipStream_t s)
 {
     const int li = c.nt == 4 ? 2 : (c.nt == 2 ? 1 : 0);
+    if (c.pw) return launch_conv_pw(c, a, s);
     if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s);
     if (c.ct) {   // direct kernel in the LDS family's K order, on that family's nt = 1 weight packing
         if (!op.w_lds[0] || a.n2 > 0) return false;
@@ -1038,7 +1039,8 @@ static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int coun
 
 static void cfg_name(const ConvCfg &c, char *buf, int n)
 {
-    if (c.lds && c.ipw > 1) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d_i%d", c.stride, c.mt, c.nt, c.ipw);
+    if (c.pw) snprintf(buf, n, "conv1x1s1_pw");
+    else if (c.lds && c.ipw > 1) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d_i%d", c.stride, c.mt, c.nt, c.ipw);
     else if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d", c.stride, c.mt, c.nt);
     else conv_cfg_name(c, buf, n);
 }
@@ -1107,6 +1109,8 @@ static int autotune_convs(irmv_engine *e)
                     const bool fam_ok = lds_ok ? ((h.lds && !h.ct && !h.deep) || (!h.lds && h.ct && !want_fuse && (!h.deep || counts[pass] == 1)))
                                                : (!h.lds && !h.ct && (!h.deep || counts[pass] == 1 || op.cfg.ks == 1));
                     bool ok = pow2 && op.cout_pad % (16 * h.nt) == 0 && h.ipw <= counts[pass] && fam_ok && (!want_fuse || h.nt == 4);
+                    if (h.pw) ok = !h.lds && !h.ct && !h.deep && h.ipw == 1 && conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW");   // one tile shape
+                    if (!h.pw && getenv("IRMV_FORCE_PW") && conv_pw_eligible(op.cfg, a)) ok = false;                                  // (parity tests)
                     if (ok && h.lds) {
                         const int li = h.nt == 4 ? 2 : (h.nt == 2 ? 1 : 0);
                         ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, h.mt, h.nt, nullptr) > 0;
@@ -1116,7 +1120,7 @@ static int autotune_convs(irmv_engine *e)
                     if (ok && h.ct) ok = op.w_lds[0] != nullptr;
                     if (ok) {
                         best_cfg = op.cfg;
-                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct;
+                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct; best_cfg.pw = h.pw;
                         best = 0.f;
                         have_hit = true;
                     } else if (getenv("IRMV_AUTOTUNE_VERBOSE") || getenv("IRMV_TUNE_WARN"))
@@ -1160,9 +1164,16 @@ static int autotune_convs(irmv_engine *e)
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             if (want_fuse && nt != 4) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false;
+                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false;
                             TRY(time_cfg(c));
                         }
+                // 1x1 layers: the persistent pointwise kernel (same operands, same k order as the direct kernel)
+                if (conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW")) {
+                    ConvCfg c = op.cfg;
+                    c.mt = 2; c.nt = 4; c.lds = false; c.ipw = 1; c.deep = false; c.ct = false; c.pw = true;
+                    TRY(time_cfg(c));
+                    if (getenv("IRMV_FORCE_PW") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
+                }
                 // A layer of the LDS family may also run on the direct kernel walking K in that family's order on its weights (ct):
                 // bit-identical, so the family rule above still holds.  Offered where the direct kernel has a chance: stride 2.
                 if (lds_ok && !want_fuse && op.w_lds[0] && op.cfg.stride == 2 && !op.cfg.cin16)

@@ -131,10 +131,13 @@ struct ConvCfg {
     int ks, stride, mt, nt; bool cin16; int act; bool out_f32; bool lds; int ipw;   // ipw: images per workgroup (LDS family)
     bool deep;   // direct kernel, latency variant: prefetch ring of 6..12 k-steps (single-frame steps)
     bool ct;     // direct kernel walking K chunk-major with the LDS family's weights: bit-identical stand-in for that family
+    bool pw;     // 1x1 layers: the persistent pointwise kernel (weights in LDS, pixel tiles software-pipelined)
 };
 // returns false if no instantiation exists for cfg
 bool launch_conv(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 const char *conv_cfg_name(const ConvCfg &cfg, char *buf, int n);
+bool conv_pw_eligible(const ConvCfg &cfg, const ConvArgs &a);
+bool launch_conv_pw(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 // LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt
 size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max);
 bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s);   // a.n2 > 0: fused 1x1 (needs stride 1, nt 4, cout 64)

@@ -327,6 +327,153 @@ static void once_per_device(unsigned long long &mask, F set_attribute)
     mask |= bit;
 }
 
+// ---------------------------------------------------------------------------
+// Pointwise (1x1) convolution as a persistent, software-pipelined GEMM.
+//
+// The direct kernel above gives a wave ONE pixel tile per lifetime: index arithmetic, a cold first load, 4..16 k-steps,
+// a SiLU epilogue as long as the matrix work (K <= 512), exit -- its waves sit in waits 40 % and issue stalls 40 % of
+// their cycles (profiles/r02_mfma.json) and it reaches 0.26-0.34 of the HBM line its arithmetic intensity puts it under.
+// Here a workgroup keeps the weights of its 64 output channels in LDS (NT x KS KiB, fragment order: conflict-free
+// ds_read_b128) and its four waves walk pixel tiles of 32 pixels with a stride of the whole grid.  Activations go
+// straight from memory into B fragments, and every fragment register is re-loaded for the wave's NEXT tile right after
+// the MFMAs that consumed it: a tile's loads are in flight for a whole tile time, under the MFMAs and the SiLU epilogue
+// of the tile before.  Same operands, same k order as the direct kernel -> bit-identical, so the autotuner may pick either.
+// ---------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_total, int wg_per_nblock)
+{
+    constexpr int MT = 2, NT = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8 *s_w = reinterpret_cast<half8 *>(smem);   // [NT][KS][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int nblk = blockIdx.y;
+    {
+        const half8 *wsrc = reinterpret_cast<const half8 *>(a.w) + (size_t)nblk * NT * KS * 64;
+        for (int e = tid; e < NT * KS * 64; e += 256) s_w[e] = wsrc[e];
+    }
+    const int HWo = a.Hout * a.Wout;
+    const int H0 = a.Hin >> a.s0.shift, W0 = a.Win >> a.s0.shift, H1 = a.Hin >> a.s1.shift, W1 = a.Win >> a.s1.shift;
+    const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    float bias[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) bias[u][i] = a.bias[(nblk * 2 + u) * 32 + g * 8 + i];
+
+    // pixel tile t of this wave: source pointers of both K segments for its two 16-pixel halves
+    const half_t *p0[MT], *p1[MT];
+    bool mv[MT];
+    auto tile_ptrs = [&](int t) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int m = (t * MT + mt) * 16 + r;
+            mv[mt] = t < tiles_total && m < a.M;
+            const int mm = mv[mt] ? m : 0;
+            const int b = mm / HWo, rem = mm - b * HWo;
+            const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+            p0[mt] = a.s0.p + ((size_t)(b * H0 + (oy >> a.s0.shift)) * W0 + (ox >> a.s0.shift)) * a.s0.ld + 8 * g;
+            p1[mt] = a.s1.p + ((size_t)(b * H1 + (oy >> a.s1.shift)) * W1 + (ox >> a.s1.shift)) * a.s1.ld + 8 * g - a.s0.C;
+        }
+    };
+    auto load_b = [&](int mt, int ks) -> half8 {
+        const int c = ks * 32;                                   // + 8 g is in the pointers
+        if (!mv[mt]) return zero8;
+        return *reinterpret_cast<const half8 *>((c < a.s0.C ? p0[mt] : p1[mt]) + c);
+    };
+
+    const int stride = wg_per_nblock * 4;
+    int t = blockIdx.x * 4 + wave;
+    half8 B[MT][KS];
+    tile_ptrs(t);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) B[mt][ks] = load_b(mt, ks);
+    __syncthreads();                                             // weights staged
+    half_t *out = static_cast<half_t *>(a.out);
+    while (t < tiles_total) {
+        size_t m_cur[MT];
+        bool mv_cur[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) { m_cur[mt] = (size_t)(t * MT + mt) * 16 + r; mv_cur[mt] = mv[mt]; }
+        tile_ptrs(t + stride);                                   // from here p0 / p1 / mv describe the NEXT tile
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // A fragments from LDS, double-buffered one k-step ahead; the scheduling barrier keeps the compiler from hoisting
+        // all KS x NT fragment reads to the top of the unrolled loop (256 VGPRs and spills without it)
+        half8 A[2][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) A[0][nt] = s_w[(nt * KS) * 64 + lane];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) A[(ks + 1) & 1][nt] = s_w[(nt * KS + ks + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks & 1][nt], B[mt][ks], acc[mt][nt], 0, 0, 0);
+                B[mt][ks] = load_b(mt, ks);                      // consumed: fetch the next tile's fragment into the same registers
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue of the direct kernel's paired-tile path: lane g holds channels u * 32 + g * 8 + [0, 8) of its pixel
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            if (!mv_cur[mt]) continue;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                float vals[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    vals[i] = acc[mt][2 * u][i] + bias[u][i];
+                    vals[4 + i] = acc[mt][2 * u + 1][i] + bias[u][4 + i];
+                }
+                half8 o;
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = (half_t)(vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i])));
+                *reinterpret_cast<half8 *>(out + m_cur[mt] * a.out_ld + (nblk * 2 + u) * 32 + g * 8) = o;
+            }
+        }
+        t += stride;
+    }
+}
+
+// eligible: 1x1, SiLU, fp16 out, pair-packed, 64 | cout, K a multiple of 32 with 4..16 k-steps, first segment a multiple of 32
+bool conv_pw_eligible(const ConvCfg &c, const ConvArgs &a)
+{
+    return c.ks == 1 && c.stride == 1 && c.act == 1 && !c.out_f32 && !c.cin16 && a.pair && a.cout_pad % 64 == 0 && a.Cin % 32 == 0 && a.s0.C % 32 == 0 &&
+           (a.ksteps == 4 || a.ksteps == 6 || a.ksteps == 8 || a.ksteps == 12 || a.ksteps == 16) && a.res == nullptr && a.n2 == 0;
+}
+
+bool launch_conv_pw(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
+{
+    if (!conv_pw_eligible(c, a)) return false;
+    const int tiles_total = (a.M + 31) / 32, nblocks = a.cout_pad / 64;
+    // ~2 workgroups per CU in total, never more workgroups than there are 4-tile rounds
+    int wg = (tiles_total + 3) / 4;
+    const int cap = (512 + nblocks - 1) / nblocks;
+    if (wg > cap) wg = cap;
+    if (wg < 1) wg = 1;
+#define IRMV_PW(KS_)                                                                                               \
+    if (a.ksteps == KS_) {                                                                                          \
+        static unsigned long long attr_done = 0;                                                                    \
+        once_per_device(attr_done, [] {                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_pw_kernel<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+        });                                                                                                         \
+        hipLaunchKernelGGL((conv1x1_pw_kernel<KS_>), dim3(wg, nblocks), dim3(256), (size_t)4 * KS_ * 1024, s, a, tiles_total, wg);            \
+        return true;                                                                                                \
+    }
+    IRMV_PW(4) IRMV_PW(6) IRMV_PW(8) IRMV_PW(12) IRMV_PW(16)
+#undef IRMV_PW
+    return false;
+}
+
 // 16-byte patch pieces a thread stages per chunk (registers are reserved for all of them): a stride-1 2-D block is at
 // most (16 MT + 2) x 18 pixels, the other schemes stage full-width rows or stride-2 patches.
 constexpr int lds_pmax(int stride, int mt, bool tile2d) { return (tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12; }

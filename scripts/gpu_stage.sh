@@ -42,6 +42,7 @@ profiles) # everything the round's profiles/ are made of, one tile table for all
          python3 scripts/collect_traffic.py $O/pmc_f/*/*_counter_collection.csv $O/pmc_w/*/*_counter_collection.csv $O/traffic.json
          python3 scripts/collect_mfma.py $O/mfma.json $O/pmc_a/*/*_counter_collection.csv $O/pmc_b/*/*_counter_collection.csv
          cp $O/prof_stats/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+         rm -rf $O/prof_stats $O/pmc_f $O/pmc_w $O/pmc_a $O/pmc_b     # raw traces: tens of MB; the reductions above are what is kept
          unset IRMV_TUNE_CACHE ;;
 stats)   export IRMV_TUNE_CACHE=$O/tune_cache.txt
          cd /tmp; export TMPDIR=/tmp
@@ -62,7 +63,7 @@ probe)   run probe_build 120 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 scrip
 trace1)  cd /tmp; export TMPDIR=/tmp
          TAG=trace run trace1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/scripts/lat_probe.py
          cd $R
-         python3 - <<'PY' > $O/trace1_summary.txt 2>&1
+         python3 - <<PY > $O/trace1_summary.txt 2>&1
 import csv, glob, collections
 f = glob.glob('$O/trace1/*/*_kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
@@ -95,6 +96,26 @@ crashprobe) cd /tmp; export TMPDIR=/tmp
          done
          cd $R ;;
 s2probe) NET=416 run s2_probe 300 python3 scripts/s2_probe.py ;;
+pmc1x1)  cd /tmp; export TMPDIR=/tmp
+         IRMV_STREAMS=1 run pmc_pw_a 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_pw_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_pw_b 300 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_pw_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_pw_c 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum --kernel-trace --output-format csv -d $O/pmc_pw_c -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         cd $R
+         python3 - <<PY > $O/pmc_pw_summary.txt 2>&1
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob('$O/pmc_pw_*/*/*_counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        if 'pw_kernel' in k or 'conv_mfma_kernel<1, 1, 4, 4' in k or 'lds_kernelILi1ELi4ELi4ELb1ELi0' in k:
+            acc[k[:60]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, c in acc.items():
+    print(k)
+    for n, v in sorted(c.items()):
+        print(f'   {n:32s} n={len(v):4d} mean {sum(v)/len(v):14.1f}')
+PY
+         cat $O/pmc_pw_summary.txt | head -80
+         rm -rf $O/pmc_pw_a $O/pmc_pw_b $O/pmc_pw_c ;;
 tunev)   SLOTS=1 run tune_verbose 300 python3 scripts/tune_verbose.py ;;
 stamps)  TAG=stamps IRMV_NMS_STAMPS=1 run nms_stamps 200 python3 scripts/lat_probe.py ;;
 headerr) run head_error 400 python3 scripts/head_error.py ;;

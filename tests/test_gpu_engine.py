@@ -396,6 +396,29 @@ def test_tile_choice_is_bitwise_neutral(blob, frame0):
     assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2])
 
 
+def test_pointwise_kernel_is_bitwise_the_direct_kernel(blob, monkeypatch):
+    """The persistent 1x1 kernel (weights in LDS, pixel tiles software-pipelined; k_conv.hip) against the direct kernel it
+    may replace: same operands, same k order -> same bits, batched (partial last tiles included: 3 frames) and single-frame."""
+    imgs = [frames.synthetic_frame(40 + i) for i in range(3)]
+    heads = {}
+    for mode in ("IRMV_FORCE_PW", "IRMV_NO_PW"):
+        monkeypatch.delenv("IRMV_FORCE_PW", raising=False)
+        monkeypatch.delenv("IRMV_NO_PW", raising=False)
+        monkeypatch.setenv(mode, "1")
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3, num_streams=1) as e:
+            names = [st["name"] for st in e.profile(0, 3)] + [st["name"] for st in e.profile(0, 1)]
+            assert any(n == "conv1x1s1_pw" for n in names) == (mode == "IRMV_FORCE_PW"), (mode, names)
+            for s, im in enumerate(imgs):
+                _load(e, s, im)
+            e.submit(0, 3); e.wait()
+            batched = [e.read_head(s).copy() for s in range(3)]
+            e.detect(1)
+            heads[mode] = batched + [e.read_head(1).copy()]
+    for a, b in zip(heads["IRMV_FORCE_PW"], heads["IRMV_NO_PW"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(heads["IRMV_FORCE_PW"][1], heads["IRMV_FORCE_PW"][3])
+
+
 def _bench_tune_cache(tmp_path, monkeypatch):
     """Seed the autotuner exactly as bench.py does (its own copy of profiles/*_tune_cache.txt)."""
     import os, shutil
