@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         if force or _stale(obj, [sp] + headers):
-            cmd = [cc] + COMMON + extra + ["-c", sp, "-o", obj]
+            cmd = [cc] + COMMON + extra + os.environ.get("IRMV_EXTRA_HIPCC_FLAGS", "").split() + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

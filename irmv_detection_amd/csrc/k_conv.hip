@@ -478,8 +478,11 @@ bool launch_conv_pw(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
 // most (16 MT + 2) x 18 pixels, the other schemes stage full-width rows or stride-2 patches.
 constexpr int lds_pmax(int stride, int mt, bool tile2d) { return (tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12; }
 
+#ifndef IRMV_LDS_WAVES
+#define IRMV_LDS_WAVES 2   // minimum waves per SIMD the register allocation aims at (A/B: scripts/gpu_stage.sh abwaves)
+#endif
 template <int STRIDE, int MT, int NT, bool TILE2D, int N2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;

@@ -13,6 +13,8 @@ def internal_name(sym):
         ks, st, mt, nt, c16, act, f32, ct, deep = m.groups()
         return (f"conv{ks}x{ks}s{st}_mt{mt}_nt{nt}" + ("_c16" if c16 == "true" else "") + ("_f32" if f32 == "true" else "") +
                 ("_deep" if deep == "true" else "") + ("_ct" if ct == "true" else ""))
+    if "conv1x1_pw_kernel" in sym:
+        return "conv1x1s1_pw"
     m = re.search(r"c2f32_kernel<(\d), (\d), (true|false)>", sym)
     if m:
         return {"0": "c2f32_ab", "1": "c2f32_a", "2": "c2f32_b"}[m.group(1)]

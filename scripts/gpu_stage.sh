@@ -116,6 +116,11 @@ for k, c in acc.items():
 PY
          cat $O/pmc_pw_summary.txt | head -80
          rm -rf $O/pmc_pw_a $O/pmc_pw_b $O/pmc_pw_c ;;
+abwaves) for w in 3 4; do
+           IRMV_EXTRA_HIPCC_FLAGS="-DIRMV_LDS_WAVES=$w" run build_w$w 600 python3 -c "from irmv_detection_amd import _build; import os; os.remove(_build.LIB_DIR + '/k_conv.o'); print(_build.build())"
+           SLOTS=64 TOP=60 run layers64_w$w 300 python3 scripts/prof_layers.py
+         done
+         run build_w2 600 python3 -c "from irmv_detection_amd import _build; import os; os.remove(_build.LIB_DIR + '/k_conv.o'); print(_build.build())" ;;
 tunev)   SLOTS=1 run tune_verbose 300 python3 scripts/tune_verbose.py ;;
 stamps)  TAG=stamps IRMV_NMS_STAMPS=1 run nms_stamps 200 python3 scripts/lat_probe.py ;;
 headerr) run head_error 400 python3 scripts/head_error.py ;;
