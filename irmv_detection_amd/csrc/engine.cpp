@@ -231,6 +231,9 @@ struct irmv_engine {
     std::vector<uint8_t> blob;
     std::vector<LayerW> layers;
     std::vector<std::vector<uint16_t>> dequant;   // int8 blobs: per layer fp16(q * scale), what LayerW::w points to
+    std::vector<std::vector<uint16_t>> merged_w;  // Detect first-stage convs of a level concatenated along cout (single-frame engines)
+    std::vector<std::vector<float>> merged_b;
+    bool merge_head0 = false;
 
     ~irmv_engine();
 };
@@ -740,17 +743,66 @@ static int build_engine(irmv_engine *e)
     }
     const char *br[3] = {"cv2", "cv3", "cv4"};
     const int mid[3] = {64, 64, 16}, off[3] = {0, kClsOff, kKptOff};
-    for (int b = 0; b < (e->nk > 0 ? 3 : 2); b++)
+    const int nbr = e->nk > 0 ? 3 : 2;
+    // Engines that never batch (every step is a single frame: the reference node's shape) run the first-stage 3x3 convs of a
+    // level's branches -- same input, 64 + 64 (+ 16) output channels -- as ONE conv: the weights are concatenated along
+    // cout (keypoint branch padded to 32 channels with zeros), the second-stage convs read channel slices of the merged
+    // output.  Same K order per output channel -> same bits; two or three launches fewer per level, and the level's input
+    // is staged once.  Batched engines keep the separate convs (their nt = 4 tiles do not divide 160 channels).
+    {
+        const char *mh = getenv("IRMV_MERGE_HEAD0");
+        e->merge_head0 = stream_share(e, S) == 1 && !e->fork_head && !(mh && mh[0] == '0');
+        if (mh && mh[0] == '1') e->merge_head0 = !e->fork_head;
+        for (int i = 0; i < 3 && e->merge_head0; i++)          // every branch conv must have the shape the merge assumes
+            for (int b = 0; b < nbr; b++) {
+                const LayerW *l0 = find_layer(e, std::string("model.22.") + br[b] + "." + std::to_string(i) + ".0");
+                if (!l0 || l0->k != 3 || l0->stride != 1 || l0->act != 1 || l0->cin != PC[i] || l0->cout != mid[b]) e->merge_head0 = false;
+            }
+    }
+    const int coff0[3] = {0, 64, 128};
+    int t_s0[3] = {-1, -1, -1};
+    if (e->merge_head0) {
+        const int cm = nbr == 3 ? 160 : 128;
+        e->merged_w.reserve(3); e->merged_b.reserve(3);
+        e->layers.reserve(e->layers.size() + 3);      // LayerW pointers handed out below stay valid
+        for (int i = 0; i < 3; i++) {
+            const LayerW *src[3] = {nullptr, nullptr, nullptr};
+            for (int b = 0; b < nbr; b++) src[b] = find_layer(e, std::string("model.22.") + br[b] + "." + std::to_string(i) + ".0");
+            const size_t per_out = (size_t)9 * PC[i];
+            e->merged_w.emplace_back((size_t)cm * per_out, (uint16_t)0);
+            e->merged_b.emplace_back((size_t)cm, 0.f);
+            for (int b = 0; b < nbr; b++) {
+                memcpy(e->merged_w.back().data() + (size_t)coff0[b] * per_out, src[b]->w, (size_t)mid[b] * per_out * 2);
+                memcpy(e->merged_b.back().data() + coff0[b], src[b]->b, (size_t)mid[b] * 4);
+            }
+            LayerW m;
+            m.name = "model.22.s0." + std::to_string(i);
+            m.cin = PC[i]; m.cout = cm; m.k = 3; m.stride = 1; m.act = 1;
+            m.w = e->merged_w.back().data(); m.b = e->merged_b.back().data();
+            e->layers.push_back(m);
+            TRY(new_tensor(e, "22.s0." + std::to_string(i), PS[i], PS[i], cm, false, &t_s0[i]));
+            TRY(add_conv(e, m.name, SegRef{P[i], 0, PC[i], 0}, SegRef{}, PS[i], PS[i], t_s0[i], 0));
+            Op &mo = e->ops.back();
+            const double real = nbr == 3 ? 144.0 : 128.0;
+            mo.flops *= real / cm;                      // algorithmic work: the zero-padded channels do not count
+            mo.lane = 1; mo.level = i;
+        }
+    }
+    for (int b = 0; b < nbr; b++)
         for (int i = 0; i < 3; i++) {
             const std::string pre = std::string("model.22.") + br[b] + "." + std::to_string(i);
             const std::string tn = std::string("22.") + br[b] + "." + std::to_string(i);
-            int t1, t2;
-            TRY(new_tensor(e, tn + ".0", PS[i], PS[i], mid[b], false, &t1));
+            int t1 = -1, t2;
             TRY(new_tensor(e, tn + ".1", PS[i], PS[i], mid[b], false, &t2));
-            TRY(add_conv(e, pre + ".0", SegRef{P[i], 0, PC[i], 0}, SegRef{}, PS[i], PS[i], t1, 0));
-            TRY(add_conv(e, pre + ".1", SegRef{t1, 0, mid[b], 0}, SegRef{}, PS[i], PS[i], t2, 0));
+            if (e->merge_head0) {
+                TRY(add_conv(e, pre + ".1", SegRef{t_s0[i], coff0[b], mid[b], 0}, SegRef{}, PS[i], PS[i], t2, 0));
+            } else {
+                TRY(new_tensor(e, tn + ".0", PS[i], PS[i], mid[b], false, &t1));
+                TRY(add_conv(e, pre + ".0", SegRef{P[i], 0, PC[i], 0}, SegRef{}, PS[i], PS[i], t1, 0));
+                TRY(add_conv(e, pre + ".1", SegRef{t1, 0, mid[b], 0}, SegRef{}, PS[i], PS[i], t2, 0));
+            }
             TRY(add_conv(e, pre + ".2", SegRef{t2, 0, mid[b], 0}, SegRef{}, PS[i], PS[i], e->head_t[i], off[b]));
-            for (size_t k = e->ops.size() - 3; k < e->ops.size(); k++) { e->ops[k].lane = 1 + b; e->ops[k].level = i; }
+            for (size_t k = e->ops.size() - (e->merge_head0 ? 2 : 3); k < e->ops.size(); k++) { e->ops[k].lane = 1 + b; e->ops[k].level = i; }
             {   // the branch's final 1x1 can ride in the epilogue of its second 3x3 (k_conv.hip, N2 > 0)
                 const int i1 = (int)e->ops.size() - 2, i2 = i1 + 1;
                 const Op &o1 = e->ops[i1], &o2 = e->ops[i2];

@@ -419,6 +419,28 @@ def test_pointwise_kernel_is_bitwise_the_direct_kernel(blob, monkeypatch):
     assert np.array_equal(heads["IRMV_FORCE_PW"][1], heads["IRMV_FORCE_PW"][3])
 
 
+def test_merged_head_first_stage_is_bitwise_the_separate_convs(blob, frame0, monkeypatch):
+    """Single-frame engines run the three first-stage Detect convs of a level as one conv (weights concatenated along
+    cout, second-stage convs reading channel slices): same bits as the separate convs, for pose and bbox-only models."""
+    from irmv_detection_amd import weights
+    for b in (blob, weights.synthetic_blob(0, nk=0)):
+        heads = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("IRMV_MERGE_HEAD0", mode)
+            with YoloEngine(None, (1280, 1024), weights_blob=b, point_source=capi.POINTS_AUTO) as e:
+                layers = [st["layer"] for st in e.profile(0, 1)]
+                assert any(l.startswith("model.22.s0.") for l in layers) == (mode == "1")
+                assert len(layers) < 60 if mode == "1" else True
+                _load(e, 0, frame0)
+                e.detect()
+                heads.append((e.read_head(0).copy(), e.read_tap("22.cv2.0.1", 0).copy(), e.read_tap("22.cv3.2.1", 0).copy()))
+        for x, y in zip(*heads):
+            assert np.array_equal(x, y)
+    monkeypatch.delenv("IRMV_MERGE_HEAD0")
+    with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=8) as e:      # batched engines keep the separate convs
+        assert not any(st["layer"].startswith("model.22.s0.") for st in e.profile(0, 4))
+
+
 def _bench_tune_cache(tmp_path, monkeypatch):
     """Seed the autotuner exactly as bench.py does (its own copy of profiles/*_tune_cache.txt)."""
     import os, shutil
