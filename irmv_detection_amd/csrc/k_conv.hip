@@ -481,7 +481,7 @@ constexpr int lds_pmax(int stride, int mt, bool tile2d) { return (tile2d && stri
 #ifndef IRMV_LDS_WAVES
 #define IRMV_LDS_WAVES 2   // minimum waves per SIMD the register allocation aims at (A/B: scripts/gpu_stage.sh abwaves)
 #endif
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -571,31 +571,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
     // large register tiles
     const half8 *w2 = reinterpret_cast<const half8 *>(a.w2) + lane;
 
-    half8 rp[PMAX], rw[WPT];
+    // register staging of the (image, chunk) steps ahead of the MFMAs: one step ahead, or two (PF2: small-M layers whose
+    // step -- 9 * MT * NT MFMAs -- is shorter than a memory round trip, so a single step of lead exposes the latency)
+    half8 rp[PF2 ? 2 : 1][PMAX], rw[PF2 ? 2 : 1][WPT];
     const size_t img_stride = (size_t)a.Hin * a.Win * a.s0.ld;
-    int l_im = 0, l_chunk = 0;   // loader position: one (image, chunk) step ahead of the MFMAs
-    auto issue_loads = [&]() {
+    int l_im = 0, l_chunk = 0;   // loader position
+    auto issue_loads = [&](half8 (&p)[PMAX], half8 (&w)[WPT]) {
         const size_t off = (size_t)l_im * img_stride + (size_t)l_chunk * 32;
 #pragma unroll
         for (int i = 0; i < PMAX; i++) {
-            rp[i] = zero8;
-            if (val_p[i]) rp[i] = *reinterpret_cast<const half8 *>(src_p[i] + off);
+            p[i] = zero8;
+            if (val_p[i]) p[i] = *reinterpret_cast<const half8 *>(src_p[i] + off);
         }
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             const int e = tid + i * 256;
-            if (e < 9 * NT * 64) rw[i] = wsrc[(size_t)l_chunk * (9 * NT * 64) + e];
+            if (e < 9 * NT * 64) w[i] = wsrc[(size_t)l_chunk * (9 * NT * 64) + e];
         }
         if (++l_chunk == chunks) { l_chunk = 0; l_im++; }
     };
-    auto write_lds = [&]() {
+    auto write_lds = [&](const half8 (&p)[PMAX], const half8 (&w)[WPT]) {
 #pragma unroll
         for (int i = 0; i < PMAX; i++)
-            if (use_p[i]) *reinterpret_cast<half8 *>(s_patch + dst_p[i]) = rp[i];
+            if (use_p[i]) *reinterpret_cast<half8 *>(s_patch + dst_p[i]) = p[i];
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             const int e = tid + i * 256;
-            if (e < 9 * NT * 64) s_w[e] = rw[i];
+            if (e < 9 * NT * 64) s_w[e] = w[i];
         }
     };
 
@@ -684,11 +686,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
 
     const int steps = nimg * chunks;
     int c_im = 0, c_chunk = 0;
-    issue_loads();
-    for (int s = 0; s < steps; s++) {
-        write_lds();
-        __syncthreads();
-        if (s + 1 < steps) issue_loads();   // in flight under the MFMAs (and the epilogue) below
+    auto mma_step = [&]() {
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int kh = tap / 3, kw = tap - kh * 3;
@@ -709,6 +707,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
             store_tile(img + c_im);
             c_chunk = 0;
             c_im++;
+        }
+    };
+    if constexpr (!PF2) {
+        issue_loads(rp[0], rw[0]);
+        for (int s = 0; s < steps; s++) {
+            write_lds(rp[0], rw[0]);
+            __syncthreads();
+            if (s + 1 < steps) issue_loads(rp[0], rw[0]);   // in flight under the MFMAs (and the epilogue) below
+            mma_step();
+        }
+    } else {
+        issue_loads(rp[0], rw[0]);
+        if (steps > 1) issue_loads(rp[1], rw[1]);
+        for (int s = 0; s < steps; s += 2) {
+            write_lds(rp[0], rw[0]);
+            __syncthreads();
+            if (s + 2 < steps) issue_loads(rp[0], rw[0]);   // two steps ahead
+            mma_step();
+            if (s + 1 < steps) {
+                write_lds(rp[1], rw[1]);
+                __syncthreads();
+                if (s + 3 < steps) issue_loads(rp[1], rw[1]);
+                mma_step();
+            }
         }
     }
 }
@@ -756,23 +778,35 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
     return g.bytes;
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false>
 static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int ipw, const LdsGeom &g, hipStream_t s)
 {
     static unsigned long long attr_done = 0;   // per instantiation: devices whose dynamic-LDS limit has been raised
     once_per_device(attr_done, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int groups = (batch + ipw - 1) / ipw;
-    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
                        wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch);
 }
 
-bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s)
+bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2)
 {
     const LdsGeom g = lds_geom(a, stride, mt, nt);
     if (!g.bytes) return false;
     if (ipw < 1) ipw = 1;
+    if (pf2) {   // two-steps-ahead staging: the small pixel tiles (MT = 1), plain epilogue
+        if (mt != 1 || a.n2 > 0) return false;
+#define IRMV_LDS_P(ST_, NT_)                                                                     \
+        if (stride == ST_ && nt == NT_) {                                                        \
+            if (g.tile2d) launch_lds_inst<ST_, 1, NT_, true, 0, true>(a, wl, batch, ipw, g, s);  \
+            else launch_lds_inst<ST_, 1, NT_, false, 0, true>(a, wl, batch, ipw, g, s);          \
+            return true;                                                                         \
+        }
+        IRMV_LDS_P(1, 1) IRMV_LDS_P(1, 2) IRMV_LDS_P(1, 4) IRMV_LDS_P(2, 1) IRMV_LDS_P(2, 2) IRMV_LDS_P(2, 4)
+#undef IRMV_LDS_P
+        return false;
+    }
     if (a.n2 > 0) {   // fused trailing 1x1: the workgroup must own all 64 channels of every pixel
         if (stride != 1 || nt != 4 || a.cout_pad != 64 || !a.pair || a.res) return false;
 #define IRMV_LDS_F(MT_, N2_)                                                                   \
