@@ -42,7 +42,18 @@ profiles) # everything the round's profiles/ are made of, one tile table for all
          python3 scripts/collect_traffic.py $O/pmc_f/*/*_counter_collection.csv $O/pmc_w/*/*_counter_collection.csv $O/traffic.json
          python3 scripts/collect_mfma.py $O/mfma.json $O/pmc_a/*/*_counter_collection.csv $O/pmc_b/*/*_counter_collection.csv
          cp $O/prof_stats/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
-         rm -rf $O/prof_stats $O/pmc_f $O/pmc_w $O/pmc_a $O/pmc_b     # raw traces: tens of MB; the reductions above are what is kept
+         cd /tmp
+         IRMV_STREAMS=1 run prof_stats1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats1 -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 20
+         cd $R
+         cp $O/prof_stats1/*/*_kernel_stats.csv $O/kernel_stats_single_stream.csv 2>/dev/null
+         rm -rf $O/prof_stats1 $O/prof_stats $O/pmc_f $O/pmc_w $O/pmc_a $O/pmc_b     # raw traces: tens of MB; the reductions above are what is kept
+         unset IRMV_TUNE_CACHE ;;
+stats1)  export IRMV_TUNE_CACHE=$R/profiles/r02_tune_cache.txt   # single-stream eager trace with the committed tile table
+         cd /tmp; export TMPDIR=/tmp
+         IRMV_STREAMS=1 run prof_stats1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats1 -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 20
+         cd $R
+         cp $O/prof_stats1/*/*_kernel_stats.csv $O/kernel_stats_single_stream.csv 2>/dev/null
+         rm -rf $O/prof_stats1
          unset IRMV_TUNE_CACHE ;;
 stats)   export IRMV_TUNE_CACHE=$O/tune_cache.txt
          cd /tmp; export TMPDIR=/tmp
