@@ -17,6 +17,7 @@
 
 #include <cstdio>
 #include <mutex>
+#include <type_traits>
 
 namespace irmv {
 
@@ -62,6 +63,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // bias of this lane's output channels, fetched with the first operands: read inside the epilogue it costs a memory
+    // round trip per output block (a load after a store waits for the store: bias and output may alias for all the
+    // compiler knows)
+    f32x4 bs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int t = nt0 + nt;
+        bs[nt] = *reinterpret_cast<const f32x4 *>(a.bias + (a.pair ? ((t >> 1) * 32 + g * 8 + (t & 1) * 4) : (t * 16 + g * 4)));
+    }
 
     const half8 *wp = reinterpret_cast<const half8 *>(a.w) + (size_t)nt0 * a.ksteps * 64 + lane;
     const int H0 = a.Hin >> a.s0.shift, W0 = a.Win >> a.s0.shift;
@@ -156,8 +167,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                     float vals[8];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        vals[i] = acc[mt][2 * u][i] + a.bias[c0 + i];
-                        vals[4 + i] = acc[mt][2 * u + 1][i] + a.bias[c0 + 4 + i];
+                        vals[i] = acc[mt][2 * u][i] + bs[2 * u][i];
+                        vals[4 + i] = acc[mt][2 * u + 1][i] + bs[2 * u + 1][i];
                     }
                     if (ACT == 1) {
 #pragma unroll
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             const int c0 = a.pair ? ((t >> 1) * 32 + g * 8 + (t & 1) * 4) : (t * 16 + g * 4);
             float vals[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) vals[i] = acc[mt][nt][i] + a.bias[c0 + i];
+            for (int i = 0; i < 4; i++) vals[i] = acc[mt][nt][i] + bs[nt][i];
             if (ACT == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
@@ -478,6 +489,19 @@ bool launch_conv_pw(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
 // most (16 MT + 2) x 18 pixels, the other schemes stage full-width rows or stride-2 patches.
 constexpr int lds_pmax(int stride, int mt, bool tile2d) { return (tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12; }
 
+#ifndef IRMV_ABL
+#define IRMV_ABL 0   // timing ablations of conv3x3_lds_kernel (scripts/probes/conv_probe.cpp); results are wrong with any bit set:
+#endif               // 1 weights staged once, 2 patch staged once, 4 no MFMAs, 8 no SiLU, 16 no output stores
+#ifndef IRMV_EXP
+#define IRMV_EXP 0   // structural experiments of the same probe: 1 late epilogue, 2 staggered second workgroup per CU
+#endif
+#if IRMV_EXP & 4
+__device__ unsigned long long g_phase[16];
+#endif
+#if IRMV_EXP & 2
+__device__ int g_cu_arrivals[4096];
+__device__ int g_stagger_sleeps = 0;
+#endif
 #ifndef IRMV_LDS_WAVES
 #define IRMV_LDS_WAVES 2   // minimum waves per SIMD the register allocation aims at (A/B: scripts/gpu_stage.sh abwaves)
 #endif
@@ -535,6 +559,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
     }
     unsigned char *s_patch = smem;
     half8 *s_w = reinterpret_cast<half8 *>(smem + (size_t)a_patch_bytes);
+    // epilogue constants, staged once: bias of this workgroup's 16 NT channels, then (N2 > 0) the fused 1x1's bias and its
+    // A fragments.  Read from global memory inside the epilogue they cost a memory round trip per 16 x 32 output block:
+    // a load after a store has to wait for the store (the compiler cannot prove bias and output apart), and every wait on
+    // a load also waits for the staging loads in flight ahead of it.
+    float *s_bias = reinterpret_cast<float *>(smem + (size_t)a_patch_bytes + 9 * NT * 1024);
+    float *s_bias2 = s_bias + 64;
+    half8 *s_w2 = reinterpret_cast<half8 *>(s_bias + 128);
+    if constexpr (NT % 2 == 0) {
+        if (tid < NT * 16) s_bias[tid] = a.bias[blockIdx.y * NT * 16 + tid];
+    } else {   // one tile: s_bias[4 g + i] = bias of the channel lane group g holds in register i
+        const int t = blockIdx.y;
+        if (tid < 16) s_bias[tid] = a.bias[a.pair ? ((t >> 1) * 32 + (tid >> 2) * 8 + (t & 1) * 4 + (tid & 3)) : (t * 16 + tid)];
+    }
+    if constexpr (N2 > 0) {
+        if (tid < N2 * 16) s_bias2[tid] = a.bias2[tid];
+        for (int e = tid; e < N2 * 2 * 64; e += 256) s_w2[e] = reinterpret_cast<const half8 *>(a.w2)[e];
+    }
     const int chunks = a.Cin >> 5;
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -566,25 +607,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
     }
     const half8 *wsrc = reinterpret_cast<const half8 *>(wl) + (size_t)nblk * chunks * (9 * NT * 64);
 
-    // fused trailing 1x1 (N2 > 0): its A fragments (1 KiB each, L1-resident) are fetched where they are used, in the
-    // epilogue -- held across the main loop they cost 8 VGPRs per 16 output channels and pushed the N2 = 4 tiles off the
-    // large register tiles
-    const half8 *w2 = reinterpret_cast<const half8 *>(a.w2) + lane;
+    // fused trailing 1x1 (N2 > 0): its A fragments are read from LDS where they are used, in the epilogue -- held across
+    // the main loop they cost 8 VGPRs per 16 output channels and pushed the N2 = 4 tiles off the large register tiles
+    const half8 *w2 = s_w2 + lane;
 
     // register staging of the (image, chunk) steps ahead of the MFMAs: one step ahead, or two (PF2: small-M layers whose
     // step -- 9 * MT * NT MFMAs -- is shorter than a memory round trip, so a single step of lead exposes the latency)
     half8 rp[PF2 ? 2 : 1][PMAX], rw[PF2 ? 2 : 1][WPT];
     const size_t img_stride = (size_t)a.Hin * a.Win * a.s0.ld;
     int l_im = 0, l_chunk = 0;   // loader position
+    int c_im = 0, c_chunk = 0;   // consumer position
     auto issue_loads = [&](half8 (&p)[PMAX], half8 (&w)[WPT]) {
         const size_t off = (size_t)l_im * img_stride + (size_t)l_chunk * 32;
 #pragma unroll
         for (int i = 0; i < PMAX; i++) {
+            if ((IRMV_ABL & 2) && (l_im | l_chunk)) break;
             p[i] = zero8;
             if (val_p[i]) p[i] = *reinterpret_cast<const half8 *>(src_p[i] + off);
         }
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
+            if ((IRMV_ABL & 1) && (l_im | l_chunk)) break;
             const int e = tid + i * 256;
             if (e < 9 * NT * 64) w[i] = wsrc[(size_t)l_chunk * (9 * NT * 64) + e];
         }
@@ -592,10 +635,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
     };
     auto write_lds = [&](const half8 (&p)[PMAX], const half8 (&w)[WPT]) {
 #pragma unroll
-        for (int i = 0; i < PMAX; i++)
+        for (int i = 0; i < PMAX; i++) {
+            if ((IRMV_ABL & 2) && (c_im | c_chunk)) break;
             if (use_p[i]) *reinterpret_cast<half8 *>(s_patch + dst_p[i]) = p[i];
+        }
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
+            if ((IRMV_ABL & 1) && (c_im | c_chunk)) break;
             const int e = tid + i * 256;
             if (e < 9 * NT * 64) s_w[e] = w[i];
         }
@@ -617,6 +663,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
 #pragma unroll
             for (int t2 = 0; t2 < N2; t2++) { W2[t2][0] = w2[(t2 * 2 + 0) * 64]; W2[t2][1] = w2[(t2 * 2 + 1) * 64]; }
         }
+        // bias: LDS -> registers once per image; shortcut: every block's load issued before the first store
+        float bs[NT % 2 == 0 ? NT / 2 : 1][8];
+        if constexpr (NT % 2 == 0) {
+#pragma unroll
+            for (int u = 0; u < NT / 2; u++) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(s_bias + u * 32 + g * 8), b1 = *reinterpret_cast<const f32x4 *>(s_bias + u * 32 + g * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { bs[u][i] = b0[i]; bs[u][4 + i] = b1[i]; }
+            }
+        } else {
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(s_bias + g * 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) bs[0][i] = b0[i];
+        }
+        half8 rv8[NT % 2 == 0 ? MT : 1][NT % 2 == 0 ? NT / 2 : 1];
+        half4 rv4[MT];
+        if (a.res) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const size_t m = (size_t)im * HWo + mloc[mt];
+                if constexpr (NT % 2 == 0) {
+#pragma unroll
+                    for (int u = 0; u < NT / 2; u++) rv8[mt][u] = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + (nt0 / 2 + u) * 32 + g * 8);
+                } else {
+                    const int c0 = a.pair ? ((nt0 >> 1) * 32 + g * 8 + (nt0 & 1) * 4) : (nt0 * 16 + g * 4);
+                    rv4[mt] = *reinterpret_cast<const half4 *>(a.res + m * a.res_ld + c0);
+                }
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             // N2 > 0: the fused 1x1's MFMAs must run with every lane (their A rows live in all 64 lanes; inside a divergent
@@ -632,19 +707,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
                         float vals[8];
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            vals[i] = acc[mt][2 * u][i] + a.bias[c0 + i];
-                            vals[4 + i] = acc[mt][2 * u + 1][i] + a.bias[c0 + 4 + i];
+                            vals[i] = acc[mt][2 * u][i] + bs[u][i];
+                            vals[4 + i] = acc[mt][2 * u + 1][i] + bs[u][4 + i];
                         }
 #pragma unroll
-                        for (int i = 0; i < 8; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
+                        for (int i = 0; i < 8; i++) if (!(IRMV_ABL & 8)) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
                         if (a.res) {
-                            const half8 rv = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + c0);
 #pragma unroll
-                            for (int i = 0; i < 8; i++) vals[i] += (float)rv[i];
+                            for (int i = 0; i < 8; i++) vals[i] += (float)rv8[mt][u][i];
                         }
 #pragma unroll
                         for (int i = 0; i < 8; i++) ov[u][i] = (half_t)vals[i];
-                        if constexpr (N2 == 0) *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = ov[u];
+                        if constexpr (N2 == 0) if (!(IRMV_ABL & 16) || ov[u][0] == (half_t)123.0f) *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = ov[u];
                     }
                     if constexpr (N2 > 0) {
                         // With the paired-tile packing lane (g, r) now holds channels u*32 + 8g + [0, 8) of pixel r: exactly the
@@ -656,9 +730,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
                             c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][0], ov[0], c2, 0, 0, 0);
                             c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][1], ov[1], c2, 0, 0, 0);
                             const int co = t2 * 16 + g * 4;
+                            const f32x4 b2 = *reinterpret_cast<const f32x4 *>(s_bias2 + co);
                             if (mv[mt])
-                                *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) =
-                                    (f32x4){c2[0] + a.bias2[co], c2[1] + a.bias2[co + 1], c2[2] + a.bias2[co + 2], c2[3] + a.bias2[co + 3]};
+                                *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) = (f32x4){c2[0] + b2[0], c2[1] + b2[1], c2[2] + b2[2], c2[3] + b2[3]};
                         }
                     }
                 } else {
@@ -667,13 +741,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
                     float vals[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        vals[i] = acc[mt][0][i] + a.bias[c0 + i];
+                        vals[i] = acc[mt][0][i] + bs[0][i];
                         vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
                     }
                     if (a.res) {
-                        const half4 rv = *reinterpret_cast<const half4 *>(a.res + m * a.res_ld + c0);
 #pragma unroll
-                        for (int i = 0; i < 4; i++) vals[i] += (float)rv[i];
+                        for (int i = 0; i < 4; i++) vals[i] += (float)rv4[mt][i];
                     }
                     *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) =
                         (half4){(half_t)vals[0], (half_t)vals[1], (half_t)vals[2], (half_t)vals[3]};
@@ -685,10 +758,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
     };
 
     const int steps = nimg * chunks;
-    int c_im = 0, c_chunk = 0;
-    auto mma_step = [&]() {
+    // The staging loads of the NEXT step ride inside this step's tap loop, a few per tap (SPREAD): issued in one burst
+    // after the barrier they fill the CU's vector-memory queue (17 wave-instructions of 1 KiB against 64 B/clk) and the
+    // wave sits in the issue stall instead of starting its MFMAs.  The last step re-loads its own pieces (no branch).
+    constexpr int NPIECE = PMAX + WPT, PER_TAP = (NPIECE + 8) / 9;
+    auto taps = [&](auto spread) {
+        constexpr bool SPREAD = decltype(spread)::value;
+        size_t off = 0;
+        if constexpr (SPREAD) {
+            if (l_im == nimg) { l_im = nimg - 1; l_chunk = chunks - 1; }
+            off = (size_t)l_im * img_stride + (size_t)l_chunk * 32;
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
+            if constexpr (SPREAD) {
+#pragma unroll
+                for (int k = 0; k < PER_TAP; k++) {
+                    const int j = tap * PER_TAP + k;
+                    if (j < PMAX) {
+                        rp[0][j] = zero8;
+                        if (val_p[j]) rp[0][j] = *reinterpret_cast<const half8 *>(src_p[j] + off);
+                    } else if (j < NPIECE) {
+                        const int e = tid + (j - PMAX) * 256;
+                        if (e < 9 * NT * 64) rw[0][j - PMAX] = wsrc[(size_t)l_chunk * (9 * NT * 64) + e];
+                    }
+                }
+            }
             const int kh = tap / 3, kw = tap - kh * 3;
             const int toff = (kh * PW + kw) * pix_stride(STRIDE);
             half8 A[NT], B[MT];
@@ -700,8 +795,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[nt], B[mt], acc[mt][nt], 0, 0, 0);
+                    if (!(IRMV_ABL & 4)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[nt], B[mt], acc[mt][nt], 0, 0, 0);
+            if constexpr (SPREAD) __builtin_amdgcn_sched_barrier(0x38f);   // everything but vector-memory instructions may cross
         }
+        if constexpr (SPREAD) {
+            if (++l_chunk == chunks) { l_chunk = 0; l_im++; }
+        }
+    };
+    auto mma_step = [&]() {
+        taps(std::false_type{});
         __syncthreads();
         if (++c_chunk == chunks) {
             store_tile(img + c_im);
@@ -709,13 +811,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
             c_im++;
         }
     };
+#if IRMV_EXP & 2
+    {   // experiment: the second workgroup to arrive on a CU starts half a step late
+        __shared__ int s_late;
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            const unsigned idx = ((xcc & 15) << 8) | ((hw >> 8) & 0xff);   // xcc | se, sh, cu
+            s_late = atomicAdd(&g_cu_arrivals[idx], 1) & 1;
+        }
+        __syncthreads();
+        if (s_late)
+            for (int i = 0; i < g_stagger_sleeps; i++) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+#if IRMV_EXP & 1
+    if constexpr (!PF2) {   // experiment: an image's epilogue runs at the start of the next step, between its staging barrier and its loads
+        issue_loads(rp[0], rw[0]);
+        int pend_im = -1;
+        for (int s = 0; s < steps; s++) {
+            write_lds(rp[0], rw[0]);
+            __syncthreads();
+            if (pend_im >= 0) { store_tile(pend_im); pend_im = -1; }
+            if (s + 1 < steps) issue_loads(rp[0], rw[0]);
+            taps(std::false_type{});
+            __syncthreads();
+            if (++c_chunk == chunks) { pend_im = img + c_im; c_chunk = 0; c_im++; }
+        }
+        if (pend_im >= 0) store_tile(pend_im);
+        return;
+    }
+#endif
+#if IRMV_EXP & 4
+    if constexpr (!PF2) {   // experiment: phase cycles of wave 0 (s_memtime), summed over the workgroups
+        long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const long long t_begin = clock64(), w_begin = wall_clock64();
+        long long t_prev = t_begin;
+        auto stamp = [&](int k) { const long long t = clock64(); t_acc[k] += t - t_prev; t_prev = t; };
+        issue_loads(rp[0], rw[0]);
+        stamp(0);
+        for (int s = 0; s < steps; s++) {
+            write_lds(rp[0], rw[0]);
+            stamp(1);
+            __syncthreads();
+            stamp(2);
+#if IRMV_EXP & 8
+            if (s + 1 < steps) issue_loads(rp[0], rw[0]);
+            stamp(3);
+            taps(std::false_type{});
+#else
+            stamp(3);
+            taps(std::true_type{});
+#endif
+            stamp(4);
+            __syncthreads();
+            stamp(5);
+            if (++c_chunk == chunks) { store_tile(img + c_im); c_chunk = 0; c_im++; stamp(6); }
+        }
+        if (tid == 0) {
+            for (int k = 0; k < 7; k++) atomicAdd(&g_phase[k], (unsigned long long)t_acc[k]);
+            atomicAdd(&g_phase[8], (unsigned long long)(clock64() - t_begin));
+            atomicAdd(&g_phase[9], (unsigned long long)(wall_clock64() - w_begin));
+            atomicAdd(&g_phase[10], 1ull);
+        }
+        return;
+    }
+#endif
     if constexpr (!PF2) {
         issue_loads(rp[0], rw[0]);
         for (int s = 0; s < steps; s++) {
             write_lds(rp[0], rw[0]);
             __syncthreads();
-            if (s + 1 < steps) issue_loads(rp[0], rw[0]);   // in flight under the MFMAs (and the epilogue) below
-            mma_step();
+            if constexpr (MT == 4 && !(IRMV_EXP & 8)) {
+                taps(std::true_type{});                          // next step's loads spread over the taps
+            } else {   // small tiles: the burst is short and the spread costs more than it saves (measured)
+                if (s + 1 < steps) issue_loads(rp[0], rw[0]);
+                taps(std::false_type{});
+            }
+            __syncthreads();
+            if (++c_chunk == chunks) {
+                store_tile(img + c_im);
+                c_chunk = 0;
+                c_im++;
+            }
         }
     } else {
         issue_loads(rp[0], rw[0]);
@@ -765,7 +942,7 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt)
     }
     if ((size_t)pr * pw * 4 > (size_t)lds_pmax(stride, mt, g.tile2d) * 256) return g;   // staging plan: pieces per thread
     g.patch_bytes = pr * pw * pix_stride(stride);
-    const size_t bytes = (size_t)g.patch_bytes + (size_t)9 * nt * 1024;
+    const size_t bytes = (size_t)g.patch_bytes + (size_t)9 * nt * 1024 + 512 + (size_t)a.n2 * 2048;   // + bias, bias2, fused 1x1 fragments
     if (bytes > 80 * 1024) return g;                            // two or more workgroups per CU
     g.bytes = bytes;
     return g;
