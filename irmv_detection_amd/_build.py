@@ -23,6 +23,7 @@ SOURCES = [
     ("k_conv.hip", []),
     ("k_post.hip", ["-ffp-contract=off"]),
     ("k_light.hip", ["-ffp-contract=off"]),
+    ("k_shuffle.hip", []),
     ("engine.cpp", ["-x", "hip"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",

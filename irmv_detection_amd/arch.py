@@ -1,4 +1,4 @@
-"""YOLOv8n conv inventory for the armor-detection hot path.
+"""YOLOv8n conv inventory for the armor-detection hot path (and its ShuffleNetV2-backbone variant).
 
 The reference runs an opaque serialized TensorRT engine (reference
 src/yolo_engine.cpp:28-36, :105); its README names the network as YOLOv8n
@@ -6,6 +6,12 @@ src/yolo_engine.cpp:28-36, :105); its README names the network as YOLOv8n
 graph (scale n: depth 0.33, width 0.25) as written down in SURVEY.md Appendix A,
 with nc = 14 armor classes (reference include/irmv_detection/armor.hpp:7) and an
 optional YOLOv8-pose style 4-keypoint branch (Appendix A.4).
+
+The reference's README also benchmarks "YOLOv8n (Shufflenet backbone)" (README.md:12,16, an external repository that
+is not available offline; BASELINE configs[4]).  `BACKBONE_SHUFFLE` is this build's stand-in for it: the YOLOv8n stem,
+neck and Detect head around ShuffleNetV2 stages (Ma et al., ECCV 2018: channel split, 1x1 -> depthwise 3x3 -> 1x1,
+concat, channel shuffle with 2 groups) of the same widths as the C2f stages they replace (64 / 128 / 256 channels at
+strides 8 / 16 / 32), so P3 / P4 / P5 keep their shapes.  Architecture [external], parity unpinned.
 
 This module is only a *table of conv layers* in canonical order.  It is the
 contract between the weight-blob writer (weights.py), the HIP engine
@@ -40,6 +46,7 @@ class ConvSpec:
     k: int
     stride: int
     act: int
+    groups: int = 1       # > 1: depthwise (groups == cout, cin == 1 = input channels per group)
 
     @property
     def n_weights(self) -> int:
@@ -60,19 +67,47 @@ def _c2f(prefix: str, c1: int, c2: int, n: int) -> List[ConvSpec]:
     return out
 
 
-def conv_specs(nc: int = NUM_CLASSES, nk: int = NUM_KPT_CH) -> List[ConvSpec]:
+BACKBONE_C2F, BACKBONE_SHUFFLE = 0, 1
+# ShuffleNetV2 stages of BACKBONE_SHUFFLE: (first block index, output channels, stride-1 units after the stride-2 block)
+SHUFFLE_STAGES = ((2, 64, 1), (4, 128, 2), (7, 256, 1))
+
+
+def _shuffle_down(prefix: str, c1: int, c2: int) -> List[ConvSpec]:
+    """Stride-2 ShuffleNetV2 block: both branches see the whole input; out = shuffle(cat(b1, b2))."""
+    bc = c2 // 2
+    return [ConvSpec(f"{prefix}.b1.dw", 1, c1, 3, 2, ACT_NONE, c1), ConvSpec(f"{prefix}.b1.pw", c1, bc, 1, 1, ACT_SILU),
+            ConvSpec(f"{prefix}.b2.pw1", c1, bc, 1, 1, ACT_SILU), ConvSpec(f"{prefix}.b2.dw", 1, bc, 3, 2, ACT_NONE, bc),
+            ConvSpec(f"{prefix}.b2.pw2", bc, bc, 1, 1, ACT_SILU)]
+
+
+def _shuffle_unit(prefix: str, c: int) -> List[ConvSpec]:
+    """Stride-1 unit: x1, x2 = split(x); out = shuffle(cat(x1, b2(x2)))."""
+    bc = c // 2
+    return [ConvSpec(f"{prefix}.b2.pw1", bc, bc, 1, 1, ACT_SILU), ConvSpec(f"{prefix}.b2.dw", 1, bc, 3, 1, ACT_NONE, bc),
+            ConvSpec(f"{prefix}.b2.pw2", bc, bc, 1, 1, ACT_SILU)]
+
+
+def conv_specs(nc: int = NUM_CLASSES, nk: int = NUM_KPT_CH, backbone: int = BACKBONE_C2F) -> List[ConvSpec]:
     """All conv layers (BN folded) in canonical order: backbone, neck, then the
     Detect head branches box (cv2), cls (cv3), kpt (cv4; only when nk > 0)."""
     L: List[ConvSpec] = []
     L.append(ConvSpec("model.0.conv", 3, 16, 3, 2, ACT_SILU))
     L.append(ConvSpec("model.1.conv", 16, 32, 3, 2, ACT_SILU))
-    L += _c2f("model.2", 32, 32, 1)
-    L.append(ConvSpec("model.3.conv", 32, 64, 3, 2, ACT_SILU))
-    L += _c2f("model.4", 64, 64, 2)
-    L.append(ConvSpec("model.5.conv", 64, 128, 3, 2, ACT_SILU))
-    L += _c2f("model.6", 128, 128, 2)
-    L.append(ConvSpec("model.7.conv", 128, 256, 3, 2, ACT_SILU))
-    L += _c2f("model.8", 256, 256, 1)
+    if backbone == BACKBONE_SHUFFLE:
+        c_prev = 32
+        for first, c, units in SHUFFLE_STAGES:
+            L += _shuffle_down(f"model.{first}", c_prev, c)
+            for u in range(units):
+                L += _shuffle_unit(f"model.{first + 1 + u}", c)
+            c_prev = c
+    else:
+        L += _c2f("model.2", 32, 32, 1)
+        L.append(ConvSpec("model.3.conv", 32, 64, 3, 2, ACT_SILU))
+        L += _c2f("model.4", 64, 64, 2)
+        L.append(ConvSpec("model.5.conv", 64, 128, 3, 2, ACT_SILU))
+        L += _c2f("model.6", 128, 128, 2)
+        L.append(ConvSpec("model.7.conv", 128, 256, 3, 2, ACT_SILU))
+        L += _c2f("model.8", 256, 256, 1)
     L.append(ConvSpec("model.9.cv1", 256, 128, 1, 1, ACT_SILU))
     L.append(ConvSpec("model.9.cv2", 512, 256, 1, 1, ACT_SILU))
     L += _c2f("model.12", 384, 128, 1)
@@ -110,14 +145,18 @@ def num_anchors(net: int = NET_SIZE) -> int:
     return sum(h * w for h, w, _ in level_shapes(net))
 
 
-def conv_out_hw(net: int = NET_SIZE):
+def conv_out_hw(net: int = NET_SIZE, backbone: int = BACKBONE_C2F):
     """name -> output spatial size, used for FLOP accounting."""
     hw = {}
     s2, s4, s8, s16, s32 = net // 2, net // 4, net // 8, net // 16, net // 32
-    for sp in conv_specs():
+    for sp in conv_specs(backbone=backbone):
         n = sp.name
         idx = int(n.split(".")[1])
-        if idx == 0:
+        if backbone == BACKBONE_SHUFFLE and 2 <= idx <= 8:
+            out = s8 if idx <= 3 else (s16 if idx <= 6 else s32)
+            down = idx in (2, 4, 7)
+            hw[n] = out * 2 if (down and n.endswith("b2.pw1")) else out   # a stride-2 block's first 1x1 runs at the input size
+        elif idx == 0:
             hw[n] = s2
         elif idx in (1, 2):
             hw[n] = s4
@@ -133,11 +172,11 @@ def conv_out_hw(net: int = NET_SIZE):
     return hw
 
 
-def flops_per_frame(net: int = NET_SIZE, nc: int = NUM_CLASSES, nk: int = NUM_KPT_CH) -> int:
+def flops_per_frame(net: int = NET_SIZE, nc: int = NUM_CLASSES, nk: int = NUM_KPT_CH, backbone: int = BACKBONE_C2F) -> int:
     """2 * MACs over every conv of one frame (8.096 GFLOP at
     640, nc = 14, no kpt head; 8.343 GFLOP with the 4-kpt head)."""
-    hw = conv_out_hw(net)
+    hw = conv_out_hw(net, backbone)
     tot = 0
-    for sp in conv_specs(nc, nk):
+    for sp in conv_specs(nc, nk, backbone):
         tot += 2 * hw[sp.name] ** 2 * sp.cout * sp.cin * sp.k * sp.k
     return tot

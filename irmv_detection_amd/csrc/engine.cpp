@@ -74,6 +74,7 @@ struct BlobLayer { char name[32]; uint32_t cin, cout, k, stride, act, pad; uint6
 struct LayerW {
     std::string name;
     int cin, cout, k, stride, act;
+    int groups;         // > 1: depthwise (groups == cout, cin == 1)
     const uint16_t *w;  // OHWI fp16 bits (points into the blob copy)
     const float *b;
 };
@@ -133,7 +134,7 @@ struct Tensor {
 
 struct SegRef { int t = -1, coff = 0, C = 0, shift = 0; };
 
-enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2, OP_C2F32 };
+enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2, OP_C2F32, OP_DW, OP_SHUF };
 
 struct Op {
     OpKind kind;
@@ -182,6 +183,7 @@ struct SlotGroup {
 struct irmv_engine {
     irmv_engine_cfg cfg{};
     int nc = 0, nk = 0, A = 0, no = 0;
+    int backbone = 0;   // 0: C2f stages (YOLOv8n), 1: ShuffleNetV2 stages (blob header)
     int lvl_hw[3] = {0, 0, 0}, lvl_base[3] = {0, 0, 0};
     size_t frame_bytes = 0;
     hipStream_t stream = nullptr;                 // stream 0: single-slot detect(), read-backs, profile
@@ -441,6 +443,87 @@ static int add_conv(irmv_engine *e, const std::string &layer, SegRef s0, SegRef 
         if (_rc) return _rc; \
     } while (0)
 
+// Depthwise 3x3 (ShuffleNetV2 stages): weights repacked tap-major [9][C] so that a lane's 8 channels are one 16-byte load
+static int add_dw(irmv_engine *e, const std::string &layer, SegRef in, int Hin, int Win, int out_t, int out_coff)
+{
+    const LayerW *l = find_layer(e, layer);
+    if (!l) return fail(IRMV_ERR_MODEL, "weight blob has no layer " + layer);
+    if (l->groups != l->cout || l->cout != in.C) return fail(IRMV_ERR_MODEL, "layer " + layer + ": not a depthwise conv over the graph's channels");
+    Op op;
+    op.kind = OP_DW;
+    op.layer = layer;
+    op.s0 = in;
+    op.Hin = Hin; op.Win = Win; op.Hout = Hin / l->stride; op.Wout = Win / l->stride;
+    op.cin = op.cout = op.cout_pad = l->cout;
+    op.cfg.stride = l->stride;
+    op.out_t = out_t; op.out_coff = out_coff;
+    const Tensor &ot = e->tensors[out_t];
+    if (ot.H != op.Hout || ot.W != op.Wout || out_coff + l->cout > ot.C) return fail(IRMV_ERR_MODEL, "layer " + layer + ": output shape mismatch");
+    std::vector<uint16_t> w((size_t)9 * l->cout);
+    for (int c = 0; c < l->cout; c++)
+        for (int t = 0; t < 9; t++) w[(size_t)t * l->cout + c] = l->w[(size_t)c * 9 + t];
+    TRY(dev_alloc(e, (void **)&op.w_packed, w.size() * 2));
+    TRY(dev_alloc(e, (void **)&op.bias, (size_t)l->cout * 4));
+    HIP_TRY(hipMemcpy(op.w_packed, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(op.bias, l->b, (size_t)l->cout * 4, hipMemcpyHostToDevice));
+    snprintf(op.kname, sizeof op.kname, "dwconv3x3s%d", l->stride);
+    snprintf(op.kname_one, sizeof op.kname_one, "dwconv3x3s%d", l->stride);
+    op.flops = 2.0 * op.Hout * op.Wout * (double)l->cout * 9;
+    op.bytes = 2.0 * ((double)Hin * Win + (double)op.Hout * op.Wout) * l->cout + 2.0 * 9 * l->cout;
+    e->ops.push_back(op);
+    return IRMV_OK;
+}
+
+// concat + channel shuffle (two groups) of two bc-channel slices: out[2 i] = a[i], out[2 i + 1] = b[i]
+static int add_shuffle(irmv_engine *e, const std::string &name, SegRef a, SegRef b, int H, int W, int out_t)
+{
+    const Tensor &ot = e->tensors[out_t];
+    if (a.C != b.C || a.C % 4 != 0 || ot.C != 2 * a.C || ot.H != H || ot.W != W) return fail(IRMV_ERR_MODEL, name + ": shuffle shapes do not match");
+    Op op;
+    op.kind = OP_SHUF;
+    op.layer = name;
+    op.s0 = a; op.s1 = b;
+    op.Hin = op.Hout = H; op.Win = op.Wout = W;
+    op.cin = op.cout = 2 * a.C;
+    op.out_t = out_t;
+    snprintf(op.kname, sizeof op.kname, "shuffle_cat");
+    snprintf(op.kname_one, sizeof op.kname_one, "shuffle_cat");
+    op.bytes = 2.0 * 2.0 * (double)H * W * 2 * a.C;
+    e->ops.push_back(op);
+    return IRMV_OK;
+}
+
+// ShuffleNetV2 blocks (irmv_detection_amd/arch.py _shuffle_down / _shuffle_unit; the oracle's shuffle_down / shuffle_unit)
+static int add_shuffle_down(irmv_engine *e, const std::string &prefix, int in_t, int c1, int H, int W, int c2, int out_t)
+{
+    const int bc = c2 / 2, Ho = H / 2, Wo = W / 2;
+    int d1, b1, p1, d2, b2;
+    TRY(new_tensor(e, prefix + ".b1.dw", Ho, Wo, c1, false, &d1));
+    TRY(new_tensor(e, prefix + ".b1", Ho, Wo, bc, false, &b1));
+    TRY(new_tensor(e, prefix + ".b2.pw1", H, W, bc, false, &p1));
+    TRY(new_tensor(e, prefix + ".b2.dw", Ho, Wo, bc, false, &d2));
+    TRY(new_tensor(e, prefix + ".b2", Ho, Wo, bc, false, &b2));
+    TRY(add_dw(e, prefix + ".b1.dw", SegRef{in_t, 0, c1, 0}, H, W, d1, 0));
+    TRY(add_conv(e, prefix + ".b1.pw", SegRef{d1, 0, c1, 0}, SegRef{}, Ho, Wo, b1, 0));
+    TRY(add_conv(e, prefix + ".b2.pw1", SegRef{in_t, 0, c1, 0}, SegRef{}, H, W, p1, 0));
+    TRY(add_dw(e, prefix + ".b2.dw", SegRef{p1, 0, bc, 0}, H, W, d2, 0));
+    TRY(add_conv(e, prefix + ".b2.pw2", SegRef{d2, 0, bc, 0}, SegRef{}, Ho, Wo, b2, 0));
+    return add_shuffle(e, prefix + ".shuffle", SegRef{b1, 0, bc, 0}, SegRef{b2, 0, bc, 0}, Ho, Wo, out_t);
+}
+
+static int add_shuffle_unit(irmv_engine *e, const std::string &prefix, int in_t, int c, int H, int W, int out_t)
+{
+    const int bc = c / 2;
+    int p1, d2, b2;
+    TRY(new_tensor(e, prefix + ".b2.pw1", H, W, bc, false, &p1));
+    TRY(new_tensor(e, prefix + ".b2.dw", H, W, bc, false, &d2));
+    TRY(new_tensor(e, prefix + ".b2", H, W, bc, false, &b2));
+    TRY(add_conv(e, prefix + ".b2.pw1", SegRef{in_t, bc, bc, 0}, SegRef{}, H, W, p1, 0));
+    TRY(add_dw(e, prefix + ".b2.dw", SegRef{p1, 0, bc, 0}, H, W, d2, 0));
+    TRY(add_conv(e, prefix + ".b2.pw2", SegRef{d2, 0, bc, 0}, SegRef{}, H, W, b2, 0));
+    return add_shuffle(e, prefix + ".shuffle", SegRef{in_t, 0, bc, 0}, SegRef{b2, 0, bc, 0}, H, W, out_t);
+}
+
 // A C2f block with a 32-channel hidden width (model.4 / model.15 at a 640 net) runs as fused kernels (k_c2f.hip) when its
 // layers have the shapes those kernels are written for: n = 1 -> one launch, n = 2 -> two.  The layer ops stay in the
 // list as `fused_away` (read-backs of the block's internal tensors run them; they are also the bit-exactness reference).
@@ -622,9 +705,12 @@ static int build_engine(irmv_engine *e)
     TRY(new_tensor(e, "input", net, net, 4, false, &x0));
     TRY(new_tensor(e, "0", s2, s2, 16, false, &a0));
     TRY(new_tensor(e, "1", s4, s4, 32, false, &a1));
-    TRY(new_tensor(e, "2", s4, s4, 32, false, &a2));
+    const bool shuffle = e->backbone == 1;   // ShuffleNetV2 stages: blocks 2..8, P3 / P4 / P5 = tensors "3" / "6" / "8"
+    if (shuffle) TRY(new_tensor(e, "2", s8, s8, 64, false, &a2));
+    else TRY(new_tensor(e, "2", s4, s4, 32, false, &a2));
     TRY(new_tensor(e, "3", s8, s8, 64, false, &a3));
-    TRY(new_tensor(e, "4", s8, s8, 64, false, &a4));
+    if (shuffle) TRY(new_tensor(e, "4", s16, s16, 128, false, &a4));
+    else TRY(new_tensor(e, "4", s8, s8, 64, false, &a4));
     TRY(new_tensor(e, "5", s16, s16, 128, false, &a5));
     TRY(new_tensor(e, "6", s16, s16, 128, false, &a6));
     TRY(new_tensor(e, "7", s32, s32, 256, false, &a7));
@@ -679,6 +765,17 @@ static int build_engine(irmv_engine *e)
             e->ops.push_back(op);
         }
     }
+    int p3 = a4, p4 = a6, p5 = a8;   // the tensors the neck reads
+    if (shuffle) {
+        TRY(add_shuffle_down(e, "model.2", a1, 32, s4, s4, 64, a2));
+        TRY(add_shuffle_unit(e, "model.3", a2, 64, s8, s8, a3));
+        TRY(add_shuffle_down(e, "model.4", a3, 64, s8, s8, 128, a4));
+        TRY(add_shuffle_unit(e, "model.5", a4, 128, s16, s16, a5));
+        TRY(add_shuffle_unit(e, "model.6", a5, 128, s16, s16, a6));
+        TRY(add_shuffle_down(e, "model.7", a6, 128, s16, s16, 256, a7));
+        TRY(add_shuffle_unit(e, "model.8", a7, 256, s32, s32, a8));
+        p3 = a3;
+    } else {
     TRY(add_c2f(e, "model.2", SegRef{a1, 0, 32, 0}, SegRef{}, s4, s4, 32, 1, true, a2));
     {
         // model.2 as one kernel (k_c2f.hip) when its four layers have the shapes that kernel is written for
@@ -706,12 +803,13 @@ static int build_engine(irmv_engine *e)
     TRY(add_c2f(e, "model.6", SegRef{a5, 0, 128, 0}, SegRef{}, s16, s16, 128, 2, true, a6));
     TRY(add_conv(e, "model.7.conv", SegRef{a6, 0, 128, 0}, SegRef{}, s16, s16, a7, 0));
     TRY(add_c2f(e, "model.8", SegRef{a7, 0, 256, 0}, SegRef{}, s32, s32, 256, 1, true, a8));
-    TRY(add_conv(e, "model.9.cv1", SegRef{a8, 0, 256, 0}, SegRef{}, s32, s32, s9, 0));
+    }
+    TRY(add_conv(e, "model.9.cv1", SegRef{p5, 0, 256, 0}, SegRef{}, s32, s32, s9, 0));
     { Op op; op.kind = OP_POOL; op.layer = "model.9.m"; snprintf(op.kname, sizeof op.kname, "sppf_pool");
       op.bytes = (double)s32 * s32 * 128 * 2 * 4; e->ops.push_back(op); }
     TRY(add_conv(e, "model.9.cv2", SegRef{s9, 0, 512, 0}, SegRef{}, s32, s32, a9, 0));
-    TRY(add_c2f(e, "model.12", SegRef{a9, 0, 256, 1}, SegRef{a6, 0, 128, 0}, s16, s16, 128, 1, false, a12));
-    TRY(add_c2f(e, "model.15", SegRef{a12, 0, 128, 1}, SegRef{a4, 0, 64, 0}, s8, s8, 64, 1, false, a15));
+    TRY(add_c2f(e, "model.12", SegRef{a9, 0, 256, 1}, SegRef{p4, 0, 128, 0}, s16, s16, 128, 1, false, a12));
+    TRY(add_c2f(e, "model.15", SegRef{a12, 0, 128, 1}, SegRef{p3, 0, 64, 0}, s8, s8, 64, 1, false, a15));
     e->ops.back().signal = 0;
     TRY(add_conv(e, "model.16.conv", SegRef{a15, 0, 64, 0}, SegRef{}, s8, s8, a16, 0));
     TRY(add_c2f(e, "model.18", SegRef{a16, 0, 64, 0}, SegRef{a12, 0, 128, 0}, s16, s16, 128, 1, false, a18));
@@ -926,6 +1024,8 @@ static int load_blob(irmv_engine *e)
     e->dequant.reserve(h.n_layers);
     if (h.nc < 1 || h.nc > 16 || (h.nk != 0 && h.nk != 8))
         return fail(IRMV_ERR_MODEL, "unsupported head: nc must be 1..16, nk 0 or 8");
+    if (h.reserved > 1) return fail(IRMV_ERR_MODEL, "unknown backbone id in the weight blob");
+    e->backbone = (int)h.reserved;
     e->nc = (int)h.nc;
     e->nk = (int)h.nk;
     e->no = 64 + e->nc + e->nk;
@@ -939,6 +1039,9 @@ static int load_blob(irmv_engine *e)
         nm[32] = 0;
         l.name = nm;
         l.cin = bl.cin; l.cout = bl.cout; l.k = bl.k; l.stride = bl.stride; l.act = bl.act;
+        l.groups = bl.pad > 1 ? (int)bl.pad : 1;
+        if (l.groups > 1 && !(l.groups == l.cout && l.cin == 1 && l.k == 3 && l.cout % 8 == 0 && l.act == 0))
+            return fail(IRMV_ERR_MODEL, "layer " + l.name + ": only depthwise 3x3 grouped convs (no activation) are supported");
         const size_t nw = (size_t)l.cout * l.k * l.k * l.cin;
         const size_t w_bytes = h.dtype == 2 ? ((nw + 3) & ~(size_t)3) + (size_t)l.cout * 4 : nw * 2;
         if (bl.w_off + w_bytes > e->blob.size() || bl.b_off + (size_t)l.cout * 4 > e->blob.size())
@@ -1481,6 +1584,27 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             a.w_m2 = e->ops[op.sub[2]].w_packed; a.b_m2 = e->ops[op.sub[2]].bias;
             if (op.sub[3] >= 0) { a.w_cv2 = e->ops[op.sub[3]].w_packed; a.b_cv2 = e->ops[op.sub[3]].bias; }
             if (!launch_c2f32(op.mode, op.shortcut, a, count, s)) return fail(IRMV_ERR_ARG, "no fused C2f kernel for " + op.layer);
+            break;
+        }
+        case OP_DW: {
+            DwArgs a;
+            const Tensor &xt = e->tensors[op.s0.t], &ot = e->tensors[op.out_t];
+            a.x = static_cast<const half_t *>(xt.slot(first)) + op.s0.coff; a.x_ld = xt.C;
+            a.y = static_cast<half_t *>(ot.slot(first)) + op.out_coff; a.y_ld = ot.C;
+            a.w = op.w_packed; a.b = op.bias;
+            a.Hin = op.Hin; a.Win = op.Win; a.Hout = op.Hout; a.Wout = op.Wout; a.C = op.cout; a.stride = op.cfg.stride;
+            launch_dwconv3x3(a, count, s);
+            break;
+        }
+        case OP_SHUF: {
+            ShufArgs a;
+            const Tensor &at = e->tensors[op.s0.t], &bt = e->tensors[op.s1.t], &ot = e->tensors[op.out_t];
+            a.a = static_cast<const half_t *>(at.slot(first)) + op.s0.coff; a.a_ld = at.C;
+            a.b = static_cast<const half_t *>(bt.slot(first)) + op.s1.coff; a.b_ld = bt.C;
+            a.out = static_cast<half_t *>(ot.slot(first)); a.out_ld = ot.C;
+            a.bc = op.s0.C;
+            a.pixels = (size_t)count * op.Hin * op.Win;
+            launch_shuffle_cat(a, s);
             break;
         }
         case OP_CONV0: {

@@ -79,6 +79,26 @@ struct C2fArgs {
 };
 void launch_c2f2(const C2fArgs &a, int batch, hipStream_t s);
 
+// ---- ShuffleNetV2 stage operators (k_shuffle.hip) ------------------------------
+struct DwArgs {
+    const half_t *x;      // [B][Hin][Win][x_ld], already offset to the first channel
+    int x_ld;
+    half_t *y;            // [B][Hout][Wout][y_ld], already offset to the first channel
+    int y_ld;
+    const half_t *w;      // [9][C] fp16, tap-major
+    const float *b;       // [C]
+    int Hin, Win, Hout, Wout, C, stride;   // C a multiple of 8
+};
+void launch_dwconv3x3(const DwArgs &a, int batch, hipStream_t s);
+struct ShufArgs {
+    const half_t *a, *b;  // [pixels][a_ld / b_ld], already offset to the first channel
+    int a_ld, b_ld;
+    half_t *out;          // [pixels][out_ld]: out[2 i] = a[i], out[2 i + 1] = b[i], i < bc
+    int out_ld, bc;       // bc a multiple of 4
+    size_t pixels;        // batch * H * W
+};
+void launch_shuffle_cat(const ShufArgs &a, hipStream_t s);
+
 // ---- implicit-GEMM conv on MFMA ----------------------------------------------
 struct ConvSeg {
     const half_t *p;  // base pointer, already offset to the segment's first channel

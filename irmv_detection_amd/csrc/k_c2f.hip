@@ -236,6 +236,18 @@ constexpr int PS = 96;                                       // bytes per pixel 
 static_assert(R1N % 16 == 0 && R3N % 16 == 0, "tile regions are whole MFMA tiles");
 }  // namespace
 
+#ifndef IRMV_EXP
+#define IRMV_EXP 0   // 4: phase stamps for scripts/probes/c2f_probe.cpp
+#endif
+#ifndef IRMV_ABL
+#define IRMV_ABL 0   // timing ablations (results wrong): 1 no input loads in phase 1, 2 phases 2 + 3 skipped, 4 phase 4 skipped, 8 no SiLU in phase 1
+#endif
+#if IRMV_EXP & 4
+__device__ unsigned long long g_c2f_phase[16];
+#define C2F_STAMP(k) do { const long long t_ = clock64(); t_acc[k] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define C2F_STAMP(k) do { } while (0)
+#endif
 // MODE 0 = AB, 1 = A, 2 = B.  KS1 = k-steps of cv1 (Cin / 32).
 template <int MODE, int KS1, bool SHORTCUT>
 __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
@@ -253,6 +265,11 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
     const int H = a.H, W = a.W;
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
     half_t *cat = a.cat + (size_t)b * H * W * a.cat_ld;   // the block's concat buffer [H][W][cat_ld]: y0 | y1 | y2 [| y3]
+#if IRMV_EXP & 4
+    long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = clock64();
+    long long t_prev = t_begin;
+#endif
 
     if constexpr (MODE != 2) {
         // ---- 1: cv1 (1x1, Cin -> 64 = y0 | y1, SiLU) on the 12 x 20 region, B fragments straight from memory ----
@@ -284,7 +301,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             for (int ks = 0; ks < KS1; ks++) {
                 const int c = ks * 32 + 8 * g;
                 B[ks] = zero8;
-                if (inside) B[ks] = *reinterpret_cast<const half8 *>(c < a.s0.C ? p0 + c : p1 + (c - a.s0.C));
+                if (inside && !(IRMV_ABL & 1)) B[ks] = *reinterpret_cast<const half8 *>(c < a.s0.C ? p0 + c : p1 + (c - a.s0.C));
             }
         };
         half8 Bn[KS1];
@@ -312,8 +329,8 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
                 if (inside) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        o[u][i] = (half_t)silu(acc[2 * u][i] + bias[u * 8 + i]);
-                        o[u][4 + i] = (half_t)silu(acc[2 * u + 1][i] + bias[u * 8 + 4 + i]);
+                        o[u][i] = (IRMV_ABL & 8) ? (half_t)(acc[2 * u][i] + bias[u * 8 + i]) : (half_t)silu(acc[2 * u][i] + bias[u * 8 + i]);
+                        o[u][4 + i] = (IRMV_ABL & 8) ? (half_t)(acc[2 * u + 1][i] + bias[u * 8 + 4 + i]) : (half_t)silu(acc[2 * u + 1][i] + bias[u * 8 + 4 + i]);
                     }
                 }
             }
@@ -349,7 +366,9 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             if (e < R1N * 4) *reinterpret_cast<half8 *>(s_in + (e >> 2) * PS + (e & 3) * 16) = v[i];
         }
     }
+    C2F_STAMP(0);
     __syncthreads();
+    C2F_STAMP(1);
 
     // ---- 2: m.cv1 (3x3, 32 -> 32, SiLU) on the 10 x 18 region ----
     {
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
         float bias[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) bias[i] = a.b_m1[g * 8 + i];
-        for (int t = wave; t < (R2N + 15) / 16; t += 4) {
+        for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : (R2N + 15) / 16); t += 4) {
             const int m = t * 16 + r;
             const bool mv = m < R2N;
             const int mm = mv ? m : 0;
@@ -389,7 +408,9 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             }
         }
     }
+    C2F_STAMP(2);
     __syncthreads();
+    C2F_STAMP(3);
 
     // ---- 3: m.cv2 (3x3, 32 -> 32, SiLU) [+ shortcut] on the tile ----
     {
@@ -402,7 +423,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
         float bias[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) bias[i] = a.b_m2[g * 8 + i];
-        for (int t = wave; t < R3N / 16; t += 4) {
+        for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : R3N / 16); t += 4) {
             const int m = t * 16 + r;
             const int ly = m / FW, lx = m - ly * FW;
             const uint8_t *base = s_t + (ly * R2W + lx) * PS + g * 16;
@@ -432,7 +453,9 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
         }
     }
     if constexpr (MODE == 1) return;
+    C2F_STAMP(4);
     __syncthreads();
+    C2F_STAMP(5);
 
     // ---- 4: cv2 (1x1 over the concat, -> 64, SiLU) -> block output ----
     {
@@ -449,7 +472,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
 #pragma unroll
             for (int i = 0; i < 8; i++) bias[u * 8 + i] = a.b_cv2[u * 32 + g * 8 + i];
         half_t *out = a.out + (size_t)b * H * W * a.out_ld;
-        for (int t = wave; t < R3N / 16; t += 4) {
+        for (int t = wave; t < ((IRMV_ABL & 4) ? 0 : R3N / 16); t += 4) {
             const int m = t * 16 + r;
             const int ly = m / FW, lx = m - ly * FW;
             const int gy = oy0 + ly, gx = ox0 + lx;
@@ -491,6 +514,14 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             }
         }
     }
+#if IRMV_EXP & 4
+    C2F_STAMP(6);
+    if (tid == 0) {
+        for (int k = 0; k < 7; k++) atomicAdd(&g_c2f_phase[k], (unsigned long long)t_acc[k]);
+        atomicAdd(&g_c2f_phase[8], (unsigned long long)(clock64() - t_begin));
+        atomicAdd(&g_c2f_phase[10], 1ull);
+    }
+#endif
 }
 
 static std::mutex g_c2f_attr_mu;

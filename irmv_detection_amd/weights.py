@@ -8,9 +8,10 @@ a flat little-endian blob of BN-folded conv weights.
 Layout (all offsets from the start of the blob, data 16-byte aligned):
 
     header  32 B : magic "IRMW", u32 version(1), nc, nk, reg_max, n_layers,
-                   dtype (1 = fp16 weights / fp32 bias), reserved
-    table   n_layers x 72 B : char name[32]; u32 cin, cout, k, stride, act, pad;
-                   u64 w_off, b_off
+                   dtype (1 = fp16 weights / fp32 bias, 2 = int8 weights + per-channel scales),
+                   backbone (0 = YOLOv8n C2f stages, 1 = ShuffleNetV2 stages: arch.py)
+    table   n_layers x 72 B : char name[32]; u32 cin, cout, k, stride, act, groups (0 = 1;
+                   depthwise: groups == cout, cin == 1); u64 w_off, b_off
     data    per layer: weights fp16 in OHWI order [cout][kh][kw][cin], then
                    bias fp32 [cout]
 
@@ -38,6 +39,7 @@ LAYER_FMT = "<32s6I2Q"
 LAYER_SIZE = struct.calcsize(LAYER_FMT)        # 72
 
 _CALIB_PATH = os.path.join(os.path.dirname(__file__), "data", "synth_calib.json")
+_CALIB_PATH_SHUFFLE = os.path.join(os.path.dirname(__file__), "data", "synth_calib_shuffle.json")
 
 
 def _align(n: int, a: int = 16) -> int:
@@ -45,7 +47,7 @@ def _align(n: int, a: int = 16) -> int:
 
 
 def build_blob(specs: List[arch.ConvSpec], tensors: List[Tuple[np.ndarray, np.ndarray]],
-               nc: int, nk: int) -> bytes:
+               nc: int, nk: int, backbone: int = arch.BACKBONE_C2F) -> bytes:
     assert len(specs) == len(tensors)
     off = _align(HEADER_SIZE + LAYER_SIZE * len(specs))
     table = []
@@ -58,12 +60,12 @@ def build_blob(specs: List[arch.ConvSpec], tensors: List[Tuple[np.ndarray, np.nd
         b_off = off
         off = _align(off + b.nbytes)
         table.append(struct.pack(LAYER_FMT, sp.name.encode(), sp.cin, sp.cout, sp.k, sp.stride,
-                                 sp.act, 0, w_off, b_off))
+                                 sp.act, sp.groups if sp.groups > 1 else 0, w_off, b_off))
         chunks.append((w_off, w.tobytes()))
         chunks.append((b_off, b.tobytes()))
     buf = bytearray(off)
     buf[:HEADER_SIZE] = struct.pack(HEADER_FMT, MAGIC, VERSION, nc, nk, arch.REG_MAX,
-                                    len(specs), 1, 0)
+                                    len(specs), 1, backbone)
     p = HEADER_SIZE
     for t in table:
         buf[p:p + LAYER_SIZE] = t
@@ -79,14 +81,14 @@ DTYPE_FP16, DTYPE_INT8 = 1, 2
 def parse_blob(blob: bytes):
     """-> (header dict, [(ConvSpec, w fp16 OHWI, b fp32)]).  An int8 blob (dtype 2) is returned DEQUANTISED: the fp16
     weights every consumer (engine, oracle) computes with, w = fp16(q * scale)."""
-    magic, ver, nc, nk, reg_max, n_layers, dtype, _ = struct.unpack_from(HEADER_FMT, blob, 0)
+    magic, ver, nc, nk, reg_max, n_layers, dtype, backbone = struct.unpack_from(HEADER_FMT, blob, 0)
     if magic != MAGIC or ver != VERSION or dtype not in (DTYPE_FP16, DTYPE_INT8):
         raise ValueError("not an IRMW v1 blob (fp16 or int8 weights)")
     out = []
     for i in range(n_layers):
-        name, cin, cout, k, stride, act, _, w_off, b_off = struct.unpack_from(
+        name, cin, cout, k, stride, act, groups, w_off, b_off = struct.unpack_from(
             LAYER_FMT, blob, HEADER_SIZE + i * LAYER_SIZE)
-        sp = arch.ConvSpec(name.rstrip(b"\0").decode(), cin, cout, k, stride, act)
+        sp = arch.ConvSpec(name.rstrip(b"\0").decode(), cin, cout, k, stride, act, max(1, groups))
         if dtype == DTYPE_FP16:
             w = np.frombuffer(blob, np.float16, sp.n_weights, w_off).reshape(cout, k, k, cin)
         else:
@@ -95,7 +97,7 @@ def parse_blob(blob: bytes):
             w = (q.astype(np.float32) * scale[:, None, None, None]).astype(np.float16)
         b = np.frombuffer(blob, np.float32, cout, b_off)
         out.append((sp, w, b))
-    return dict(nc=nc, nk=nk, reg_max=reg_max, n_layers=n_layers, dtype=dtype), out
+    return dict(nc=nc, nk=nk, reg_max=reg_max, n_layers=n_layers, dtype=dtype, backbone=backbone), out
 
 
 def quantize_int8(w: np.ndarray):
@@ -108,7 +110,8 @@ def quantize_int8(w: np.ndarray):
     return q, scale
 
 
-def build_blob_int8(specs: List[arch.ConvSpec], tensors: List[Tuple[np.ndarray, np.ndarray]], nc: int, nk: int) -> bytes:
+def build_blob_int8(specs: List[arch.ConvSpec], tensors: List[Tuple[np.ndarray, np.ndarray]], nc: int, nk: int,
+                    backbone: int = arch.BACKBONE_C2F) -> bytes:
     """.irmw with dtype 2 (BASELINE configs[4]: int8 weights): per layer int8 OHWI weights followed (4-byte aligned) by
     the fp32 per-output-channel scales; biases stay fp32.  Half the bytes of the fp16 blob on disk, over the RCCL
     broadcast and in the host->device upload; the engine expands w = fp16(q * scale) once at load into the MFMA fragment
@@ -121,12 +124,12 @@ def build_blob_int8(specs: List[arch.ConvSpec], tensors: List[Tuple[np.ndarray, 
         off = _align(off + _align(sp.n_weights, 4) + 4 * sp.cout)
         b_off = off
         off = _align(off + 4 * sp.cout)
-        table.append(struct.pack(LAYER_FMT, sp.name.encode(), sp.cin, sp.cout, sp.k, sp.stride, sp.act, 0, w_off, b_off))
+        table.append(struct.pack(LAYER_FMT, sp.name.encode(), sp.cin, sp.cout, sp.k, sp.stride, sp.act, sp.groups if sp.groups > 1 else 0, w_off, b_off))
         chunks.append((w_off, q.tobytes()))
         chunks.append((w_off + _align(sp.n_weights, 4), scale.tobytes()))
         chunks.append((b_off, np.asarray(b, np.float32).tobytes()))
     buf = bytearray(off)
-    buf[:HEADER_SIZE] = struct.pack(HEADER_FMT, MAGIC, VERSION, nc, nk, arch.REG_MAX, len(specs), DTYPE_INT8, 0)
+    buf[:HEADER_SIZE] = struct.pack(HEADER_FMT, MAGIC, VERSION, nc, nk, arch.REG_MAX, len(specs), DTYPE_INT8, backbone)
     p = HEADER_SIZE
     for t in table:
         buf[p:p + LAYER_SIZE] = t
@@ -139,12 +142,13 @@ def build_blob_int8(specs: List[arch.ConvSpec], tensors: List[Tuple[np.ndarray, 
 def quantize_blob_int8(blob: bytes) -> bytes:
     """fp16 .irmw -> int8 .irmw (same layers, biases, head)."""
     hdr, layers = parse_blob(blob)
-    return build_blob_int8([sp for sp, _, _ in layers], [(w, b) for _, w, b in layers], hdr["nc"], hdr["nk"])
+    return build_blob_int8([sp for sp, _, _ in layers], [(w, b) for _, w, b in layers], hdr["nc"], hdr["nk"], hdr["backbone"])
 
 
-def load_calib() -> Optional[dict]:
-    if os.path.exists(_CALIB_PATH):
-        with open(_CALIB_PATH) as f:
+def load_calib(backbone: int = arch.BACKBONE_C2F) -> Optional[dict]:
+    path = _CALIB_PATH_SHUFFLE if backbone == arch.BACKBONE_SHUFFLE else _CALIB_PATH
+    if os.path.exists(path):
+        with open(path) as f:
             return json.load(f)
     return None
 
@@ -156,20 +160,20 @@ KPT_BASE = ((-1.5, 0.6), (-1.5, -0.6), (1.5, -0.6), (1.5, 0.6))
 
 
 def synthetic_tensors(seed: int = 0, nc: int = arch.NUM_CLASSES, nk: int = arch.NUM_KPT_CH,
-                      calib: Optional[dict] = None, use_calib: bool = True):
+                      calib: Optional[dict] = None, use_calib: bool = True, backbone: int = arch.BACKBONE_C2F):
     """Seeded weights.  `calib` = {"gain": {name: g}, "cls_bias": {level: b}}
     (written by tests/golden/make_calib.py); absent entries use analytic
     defaults (SiLU second moment 0.356 -> gain 1.68)."""
     if calib is None and use_calib:
-        calib = load_calib()
+        calib = load_calib(backbone)
     gains: Dict[str, float] = (calib or {}).get("gain", {})
     cls_bias: Dict[str, float] = (calib or {}).get("cls_bias", {})
     rng = np.random.Generator(np.random.PCG64(seed))
-    specs = arch.conv_specs(nc, nk)
+    specs = arch.conv_specs(nc, nk, backbone)
     tensors = []
     for sp in specs:
         fan_in = sp.cin * sp.k * sp.k
-        default_gain = 4.0 if sp.name == "model.0.conv" else 1.68
+        default_gain = 4.0 if sp.name == "model.0.conv" else (1.0 if sp.groups > 1 else 1.68)   # depthwise: no activation after it
         g = float(gains.get(sp.name, default_gain))
         w = rng.standard_normal((sp.cout, sp.k, sp.k, sp.cin), dtype=np.float32)
         b = rng.standard_normal(sp.cout, dtype=np.float32)
@@ -196,9 +200,9 @@ def synthetic_tensors(seed: int = 0, nc: int = arch.NUM_CLASSES, nk: int = arch.
 
 
 def synthetic_blob(seed: int = 0, nc: int = arch.NUM_CLASSES, nk: int = arch.NUM_KPT_CH,
-                   calib: Optional[dict] = None, use_calib: bool = True) -> bytes:
-    specs, tensors = synthetic_tensors(seed, nc, nk, calib, use_calib)
-    return build_blob(specs, tensors, nc, nk)
+                   calib: Optional[dict] = None, use_calib: bool = True, backbone: int = arch.BACKBONE_C2F) -> bytes:
+    specs, tensors = synthetic_tensors(seed, nc, nk, calib, use_calib, backbone)
+    return build_blob(specs, tensors, nc, nk, backbone)
 
 
 def model_blob_path(onnx_file_path: str) -> str:

@@ -86,12 +86,14 @@ float orc_round_f16(float f) { return round_f16(f); }
 struct orc_conv {
     char name[32];
     int cin, cout, k, stride, act;
+    int groups; /* > 1: depthwise (groups == cout, cin == 1) */
     float *w; /* [k*k][cin][cout] */
     float *b; /* [cout] */
 };
 
 struct orc_net {
     int nc, nk, n;
+    int backbone; /* 0: YOLOv8n C2f stages; 1: ShuffleNetV2 stages (irmv_detection_amd/arch.py) */
     struct orc_conv *L;
 };
 
@@ -112,6 +114,7 @@ orc_net *orc_net_load(const uint8_t *blob, size_t bytes)
     n->nc = (int)h.nc;
     n->nk = (int)h.nk;
     n->n = (int)h.n_layers;
+    n->backbone = (int)h.reserved;
     n->L = calloc(n->n, sizeof *n->L);
     for (int i = 0; i < n->n; i++) {
         struct blob_layer l;
@@ -120,6 +123,7 @@ orc_net *orc_net_load(const uint8_t *blob, size_t bytes)
         memcpy(c->name, l.name, 32);
         c->name[31] = 0;
         c->cin = l.cin; c->cout = l.cout; c->k = l.k; c->stride = l.stride; c->act = l.act;
+        c->groups = l.pad > 1 ? (int)l.pad : 1;
         size_t nw = (size_t)c->cout * c->k * c->k * c->cin;
         const size_t w_bytes = h.dtype == 2 ? ((nw + 3) & ~(size_t)3) + (size_t)c->cout * 4 : nw * 2;
         if (l.w_off + w_bytes > bytes || l.b_off + (size_t)c->cout * 4 > bytes) {
@@ -230,6 +234,82 @@ static int conv(const orc_net *n, const char *name, const T *x, int xoff, T *y, 
     return 0;
 }
 
+/* depthwise 3x3 (groups == channels), bias, no activation: y[:, :, yoff + c] = b[c] + sum_taps x[:, :, xoff + c] * w[tap][c].
+ * emu: the engine stores this tensor in fp16 like every other activation. */
+static int dwconv(const orc_net *n, const char *name, const T *x, int xoff, T *y, int yoff, int emu)
+{
+    const struct orc_conv *c = find_layer(n, name);
+    if (!c) { fprintf(stderr, "oracle: no layer %s\n", name); return -1; }
+    const int k = c->k, s = c->stride, pad = k / 2, C = c->cout;
+    const int Ho = (x->H + 2 * pad - k) / s + 1, Wo = (x->W + 2 * pad - k) / s + 1;
+    if (c->groups != C || c->cin != 1 || Ho != y->H || Wo != y->W || xoff + C > x->C || yoff + C > y->C) {
+        fprintf(stderr, "oracle: shape mismatch at %s\n", name);
+        return -1;
+    }
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < Ho * Wo; p++) {
+        const int oy = p / Wo, ox = p % Wo;
+        float *yp = y->d + (size_t)p * y->C + yoff;
+        for (int ch = 0; ch < C; ch++) {
+            float acc = c->b[ch];
+            for (int kh = 0; kh < k; kh++) {
+                const int iy = oy * s - pad + kh;
+                if (iy < 0 || iy >= x->H) continue;
+                for (int kw = 0; kw < k; kw++) {
+                    const int ix = ox * s - pad + kw;
+                    if (ix < 0 || ix >= x->W) continue;
+                    acc += x->d[((size_t)iy * x->W + ix) * x->C + xoff + ch] * c->w[(size_t)(kh * k + kw) * C + ch];
+                }
+            }
+            if (c->act == 1) acc = silu(acc);
+            yp[ch] = emu ? round_f16(acc) : acc;
+        }
+    }
+    return 0;
+}
+
+/* out[:, :, 2 i] = a[:, :, aoff + i], out[:, :, 2 i + 1] = b[:, :, boff + i]: concat + channel shuffle with two groups */
+static T shuffle_cat(const T *a, int aoff, const T *b, int boff, int bc)
+{
+    T o = talloc(a->H, a->W, 2 * bc);
+    for (int p = 0; p < o.H * o.W; p++)
+        for (int i = 0; i < bc; i++) {
+            o.d[(size_t)p * o.C + 2 * i] = a->d[(size_t)p * a->C + aoff + i];
+            o.d[(size_t)p * o.C + 2 * i + 1] = b->d[(size_t)p * b->C + boff + i];
+        }
+    return o;
+}
+
+/* ShuffleNetV2 stride-2 block (arch.py _shuffle_down): out = shuffle(cat(pw(dw(x)), pw2(dw(pw1(x))))) */
+static int shuffle_down(const orc_net *net, const char *prefix, const T *in, int c2, int emu, T *out)
+{
+    char nm[64];
+    const int bc = c2 / 2, Ho = in->H / 2, Wo = in->W / 2;
+    T d1 = talloc(Ho, Wo, in->C), b1 = talloc(Ho, Wo, bc), p1 = talloc(in->H, in->W, bc), d2 = talloc(Ho, Wo, bc), b2 = talloc(Ho, Wo, bc);
+    snprintf(nm, sizeof nm, "%s.b1.dw", prefix);  int rc = dwconv(net, nm, in, 0, &d1, 0, emu);
+    snprintf(nm, sizeof nm, "%s.b1.pw", prefix);  rc |= conv(net, nm, &d1, 0, &b1, 0, NULL, 0, emu);
+    snprintf(nm, sizeof nm, "%s.b2.pw1", prefix); rc |= conv(net, nm, in, 0, &p1, 0, NULL, 0, emu);
+    snprintf(nm, sizeof nm, "%s.b2.dw", prefix);  rc |= dwconv(net, nm, &p1, 0, &d2, 0, emu);
+    snprintf(nm, sizeof nm, "%s.b2.pw2", prefix); rc |= conv(net, nm, &d2, 0, &b2, 0, NULL, 0, emu);
+    *out = shuffle_cat(&b1, 0, &b2, 0, bc);
+    tfree(&d1); tfree(&b1); tfree(&p1); tfree(&d2); tfree(&b2);
+    return rc;
+}
+
+/* ShuffleNetV2 stride-1 unit (arch.py _shuffle_unit): x1, x2 = split(x); out = shuffle(cat(x1, pw2(dw(pw1(x2))))) */
+static int shuffle_unit(const orc_net *net, const char *prefix, const T *in, int emu, T *out)
+{
+    char nm[64];
+    const int bc = in->C / 2;
+    T p1 = talloc(in->H, in->W, bc), d2 = talloc(in->H, in->W, bc), b2 = talloc(in->H, in->W, bc);
+    snprintf(nm, sizeof nm, "%s.b2.pw1", prefix); int rc = conv(net, nm, in, bc, &p1, 0, NULL, 0, emu);
+    snprintf(nm, sizeof nm, "%s.b2.dw", prefix);  rc |= dwconv(net, nm, &p1, 0, &d2, 0, emu);
+    snprintf(nm, sizeof nm, "%s.b2.pw2", prefix); rc |= conv(net, nm, &d2, 0, &b2, 0, NULL, 0, emu);
+    *out = shuffle_cat(in, 0, &b2, 0, bc);
+    tfree(&p1); tfree(&d2); tfree(&b2);
+    return rc;
+}
+
 /* 5x5 stride-1 pad-2 max pool, slice -> slice (padding never wins: -inf) */
 static void maxpool5(const T *x, int xoff, T *y, int yoff, int C)
 {
@@ -331,6 +411,17 @@ int orc_net_forward(const orc_net *n, const float *in_chw, int net, int emu, flo
     T a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a12, a15, a16, a18, a19, a21;
     rc |= conv_new(n, "model.0.conv", &x, 16, 2, emu, &a0);  tap(&tc, "0", &a0);
     rc |= conv_new(n, "model.1.conv", &a0, 32, 2, emu, &a1); tap(&tc, "1", &a1);
+    if (n->backbone == 1) {
+        /* ShuffleNetV2 stages of the same widths: a4 (P3), a6 (P4), a8 (P5) keep their meaning; a2, a3, a5, a7 are the
+         * blocks in between (tensor names = block indices) */
+        rc |= shuffle_down(n, "model.2", &a1, 64, emu, &a2);  tap(&tc, "2", &a2);
+        rc |= shuffle_unit(n, "model.3", &a2, emu, &a4);      tap(&tc, "3", &a4);
+        rc |= shuffle_down(n, "model.4", &a4, 128, emu, &a3); tap(&tc, "4", &a3);
+        rc |= shuffle_unit(n, "model.5", &a3, emu, &a5);      tap(&tc, "5", &a5);
+        rc |= shuffle_unit(n, "model.6", &a5, emu, &a6);      tap(&tc, "6", &a6);
+        rc |= shuffle_down(n, "model.7", &a6, 256, emu, &a7); tap(&tc, "7", &a7);
+        rc |= shuffle_unit(n, "model.8", &a7, emu, &a8);      tap(&tc, "8", &a8);
+    } else {
     rc |= c2f(n, "model.2", &a1, 32, 1, 1, emu, &a2);        tap(&tc, "2", &a2);
     rc |= conv_new(n, "model.3.conv", &a2, 64, 2, emu, &a3); tap(&tc, "3", &a3);
     rc |= c2f(n, "model.4", &a3, 64, 2, 1, emu, &a4);        tap(&tc, "4", &a4);
@@ -338,6 +429,7 @@ int orc_net_forward(const orc_net *n, const float *in_chw, int net, int emu, flo
     rc |= c2f(n, "model.6", &a5, 128, 2, 1, emu, &a6);       tap(&tc, "6", &a6);
     rc |= conv_new(n, "model.7.conv", &a6, 256, 2, emu, &a7); tap(&tc, "7", &a7);
     rc |= c2f(n, "model.8", &a7, 256, 1, 1, emu, &a8);       tap(&tc, "8", &a8);
+    }
     { /* SPPF */
         T cat = talloc(a8.H, a8.W, 512);
         rc |= conv(n, "model.9.cv1", &a8, 0, &cat, 0, NULL, 0, emu);

@@ -1,4 +1,5 @@
-"""Calibrate the synthetic-weight generator (writes irmv_detection_amd/data/synth_calib.json).
+"""Calibrate the synthetic-weight generator (writes irmv_detection_amd/data/synth_calib.json, or
+synth_calib_shuffle.json with `--backbone 1`).
 
 No trained YOLOv8n weights exist offline, so parity and
 benchmarks run on seeded random weights.  Uncalibrated, 70-odd random conv
@@ -11,7 +12,7 @@ is plain data (72 gains + 3 biases); irmv_detection_amd.weights multiplies its
 seeded N(0,1) draws by them, so weight generation itself stays bit-deterministic
 and torch-free.
 
-Run:  python tests/golden/make_calib.py
+Run:  python tests/golden/make_calib.py [--backbone 1]
 """
 from __future__ import annotations
 
@@ -44,7 +45,7 @@ class CalibNet(TorchNet):
 
     def conv(self, name, x):
         sp, w, b = self.p[name]
-        y = F.conv2d(x, w, None, stride=sp.stride, padding=sp.k // 2)
+        y = F.conv2d(x, w, None, stride=sp.stride, padding=sp.k // 2, groups=sp.groups)
         parts = name.split(".")
         final = parts[1] == "22" and parts[4] == "2"
         target = 0.15 if (final and parts[2] == "cv4") else 1.0
@@ -59,13 +60,14 @@ class CalibNet(TorchNet):
 
 
 def main():
-    blob = weights.synthetic_blob(0, use_calib=False)
+    backbone = int(sys.argv[sys.argv.index("--backbone") + 1]) if "--backbone" in sys.argv else arch.BACKBONE_C2F
+    blob = weights.synthetic_blob(0, use_calib=False, backbone=backbone)
     net = CalibNet(blob)
     x = oracle.preprocess(frames.synthetic_frame(0), arch.NET_SIZE)
     net.forward(torch.from_numpy(x))
     gains = {}
-    for sp in arch.conv_specs():
-        default = 4.0 if sp.name == "model.0.conv" else 1.68
+    for sp in arch.conv_specs(backbone=backbone):
+        default = 4.0 if sp.name == "model.0.conv" else (1.0 if sp.groups > 1 else 1.68)
         gains[sp.name] = round(default * net.scale[sp.name], 6)
     lt = math.log(SCORE_THR / (1 - SCORE_THR))
     cls_bias = {}
@@ -74,7 +76,7 @@ def main():
         k = TARGET_PAIRS[lvl]
         cls_bias[lvl] = round(float(lt - 0.5 * (v[k - 1] + v[k])), 6)
     out = dict(seed=0, frame=0, score_thr=SCORE_THR, gain=gains, cls_bias=cls_bias)
-    path = os.path.join(ROOT, "irmv_detection_amd", "data", "synth_calib.json")
+    path = os.path.join(ROOT, "irmv_detection_amd", "data", "synth_calib_shuffle.json" if backbone == arch.BACKBONE_SHUFFLE else "synth_calib.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -1,0 +1,181 @@
+"""BASELINE configs[4]: the ShuffleNetV2-backbone variant (arch.BACKBONE_SHUFFLE), int8 weights, 416 x 416 input.
+
+The reference names the model only in its README (README.md:12,16 -- an external repository, unavailable offline) and
+holds no weights and no outputs for it: the architecture here is this build's stand-in ([external], SURVEY.md 8d
+"Config 4") and parity is UNPINNED -- what these tests pin is the build against itself: the C oracle against an
+independent torch-CPU statement (F.conv2d with groups, view / transpose channel shuffle), and the HIP engine against the
+oracle at the tolerances of the YOLOv8n tests (tests/test_gpu_engine.py), at 640 and at 416, fp16 and int8 blobs."""
+import numpy as np
+import pytest
+import torch
+
+from irmv_detection_amd import arch, frames, weights
+from oracle import oracle
+from torch_ref import TorchNet
+
+HEAD_TOL = 3e-2
+
+
+@pytest.fixture(scope="module")
+def sblob():
+    return weights.synthetic_blob(0, backbone=arch.BACKBONE_SHUFFLE)
+
+
+def test_layer_table_and_blob_header(sblob):
+    specs = arch.conv_specs(backbone=arch.BACKBONE_SHUFFLE)
+    names = [s.name for s in specs]
+    assert len(names) == len(set(names)) == 76
+    dws = [s for s in specs if s.groups > 1]
+    assert len(dws) == 10 and all(s.cin == 1 and s.groups == s.cout and s.k == 3 and s.act == arch.ACT_NONE for s in dws)
+    assert [s.stride for s in dws] == [2, 2, 1, 2, 2, 1, 1, 2, 2, 1]
+    hdr, layers = weights.parse_blob(sblob)
+    assert hdr["backbone"] == arch.BACKBONE_SHUFFLE and hdr["n_layers"] == 76
+    assert [sp for sp, _, _ in layers] == specs
+    assert weights.parse_blob(weights.synthetic_blob(0))[0]["backbone"] == arch.BACKBONE_C2F
+    # the head and the neck are YOLOv8n's: same layers after the backbone
+    tail = [s for s in arch.conv_specs() if int(s.name.split(".")[1]) >= 9]
+    assert specs[-len(tail):] == tail
+    assert arch.flops_per_frame(640, backbone=1) < arch.flops_per_frame(640) and arch.flops_per_frame(416, backbone=1) == 2537044224
+
+
+def test_oracle_matches_torch(sblob):
+    rng = np.random.default_rng(1)
+    x = rng.random((3, 96, 96), dtype=np.float32)
+    on, tn = oracle.Net(sblob), TorchNet(sblob)
+    h, ht = on.forward(x), tn.forward(torch.from_numpy(x)).numpy()
+    assert h.shape == ht.shape == (12 * 12 + 6 * 6 + 3 * 3, 86)
+    assert np.abs(h - ht).max() <= 1e-4 * max(1.0, np.abs(ht).max())
+    for tap in ("2", "3", "4", "5", "6", "7", "8", "15", "21"):
+        _, t = on.forward(x, tap=tap)
+        tt = tn.taps[tap][0].permute(1, 2, 0).numpy()
+        assert t.shape == tt.shape and np.abs(t - tt).max() <= 1e-4 * max(1.0, np.abs(tt).max()), tap
+
+
+def test_channel_shuffle_is_an_interleave(sblob):
+    """out[2 i] = first[i], out[2 i + 1] = second[i]: the statement the engine's shuffle_cat kernel implements"""
+    x = torch.arange(2 * 8 * 1 * 1, dtype=torch.float32).view(1, 16, 1, 1)
+    y = TorchNet.shuffle(x).view(-1).numpy()
+    assert np.array_equal(y[0::2], np.arange(8)) and np.array_equal(y[1::2], np.arange(8, 16))
+
+
+def test_oracle_fp16_emulation_and_candidates(sblob, frame0):
+    on = oracle.Net(sblob)
+    for net, lo in ((640, 100), (416, 10)):
+        x = oracle.preprocess(frames.synthetic_frame(0), net)
+        h = on.forward(x)
+        h16 = on.forward(x, emulate_fp16=True)
+        assert 0 < np.abs(h - h16).max() < 5e-2
+        d = oracle.decode_nms(h, net, 14, 8)
+        assert d["n_candidates"] >= lo and d["num_dets"] >= 5        # NMS / PnP parity on this model is not vacuous
+
+
+def test_int8_blob_keeps_backbone_and_groups(sblob):
+    q = weights.quantize_blob_int8(sblob)
+    assert len(q) < 0.56 * len(sblob)
+    h, layers = weights.parse_blob(q)
+    assert h["backbone"] == arch.BACKBONE_SHUFFLE and h["dtype"] == weights.DTYPE_INT8
+    assert [sp for sp, _, _ in layers] == arch.conv_specs(backbone=arch.BACKBONE_SHUFFLE)
+    x = oracle.preprocess(frames.synthetic_frame(1), 416)
+    deq = weights.build_blob([sp for sp, _, _ in layers], [(w, b) for _, w, b in layers], h["nc"], h["nk"], h["backbone"])
+    assert np.array_equal(oracle.Net(q).forward(x), oracle.Net(deq).forward(x))
+
+
+# ------------------------------------------------------------------------------------------------------------- GPU
+def _box_tol(stride):
+    return max(0.5, 0.05 * stride)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net", [640, 416])
+def test_engine_taps_and_head_vs_oracle(sblob, net):
+    from irmv_detection_amd.engine import YoloEngine
+    on = oracle.Net(sblob)
+    f = frames.synthetic_frame(0)
+    x = oracle.preprocess(f, net)
+    with YoloEngine(None, (1280, 1024), weights_blob=sblob, net_size=net) as e:
+        e.get_src_image_buffer()[:] = f
+        e.detect()
+        names = [k["name"] for k in e.profile(0, 1)]
+        assert any(n.startswith("dwconv3x3s2") for n in names) and any(n.startswith("dwconv3x3s1") for n in names) and "shuffle_cat" in names
+        for tap in ("1", "2", "3", "4", "5", "6", "7", "8", "9", "15", "21", "model.2.b1.dw", "model.3.b2", "model.7.b2.pw1"):
+            t_g = e.read_tap(tap, 0)
+            if tap.startswith("model."):
+                continue                     # block-internal tensors exist (shape-checked by the read); the oracle taps block outputs
+            _, t_o = on.forward(x, emulate_fp16=True, tap=tap)
+            assert t_g.shape == t_o.shape, tap
+            assert np.abs(t_g - t_o).max() <= 2 * HEAD_TOL, tap
+            assert np.abs(t_g - t_o).mean() <= 2e-3, tap
+        h = e.read_head(0)
+    assert np.abs(h - on.forward(x)).max() <= HEAD_TOL
+    assert np.abs(h - on.forward(x, emulate_fp16=True)).max() <= 2 * HEAD_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net", [640, 416])
+def test_engine_post_is_exact_on_its_own_head_and_close_end_to_end(sblob, net):
+    """decode + NMS + keypoints + PnP: bit-exact against the oracle on the engine's own head tensor; end to end against the
+    fp32 oracle the shared survivors agree within the YOLOv8n tolerances"""
+    from irmv_detection_amd.engine import YoloEngine
+    on = oracle.Net(sblob)
+    f = frames.synthetic_frame(2)
+    with YoloEngine(None, (1280, 1024), weights_blob=sblob, net_size=net) as e:
+        e.get_src_image_buffer()[:] = f
+        e.detect()
+        head = e.read_head(0).copy()
+        raw = e.read_raw(0)
+    exp = oracle.decode_nms(head, net, 14, 8)
+    assert raw["n_candidates"] == exp["n_candidates"] and raw["num_dets"] == exp["num_dets"] > 0
+    n = exp["num_dets"]
+    assert np.array_equal(raw["anchors"][:n], exp["anchors"]) and np.array_equal(raw["classes"][:n], exp["classes"])
+    assert np.array_equal(raw["boxes"][:n], exp["boxes"]) and np.array_equal(raw["kpts"][:n], exp["kpts"])
+    ref = oracle.decode_nms(on.forward(oracle.preprocess(f, net)), net, 14, 8)
+    pos = {(int(a), int(c)): i for i, (a, c) in enumerate(zip(ref["anchors"], ref["classes"]))}
+    shared = [(i, pos[(int(a), int(c))]) for i, (a, c) in enumerate(zip(exp["anchors"], exp["classes"])) if (int(a), int(c)) in pos]
+    assert len(shared) >= 0.9 * max(n, ref["num_dets"])
+    A8, A16 = (net // 8) ** 2, (net // 8) ** 2 + (net // 16) ** 2
+    for i, j in shared:
+        stride = 8 if exp["anchors"][i] < A8 else (16 if exp["anchors"][i] < A16 else 32)
+        assert np.abs(exp["boxes"][i] - ref["boxes"][j]).max() <= _box_tol(stride)
+        assert abs(exp["scores"][i] - ref["scores"][j]) <= 5e-3
+        assert np.abs(exp["kpts"][i] - ref["kpts"][j]).max() <= 0.75
+
+
+@pytest.mark.gpu
+def test_config4_int8_416_engine_equals_dequantised_blob_and_batches(sblob):
+    """configs[4] as named: ShuffleNet backbone, int8 weights, 416 x 416.  The int8 blob runs bit for bit like its
+    dequantised fp16 twin, and a batched step equals per-slot detects."""
+    from irmv_detection_amd.engine import YoloEngine
+    q = weights.quantize_blob_int8(sblob)
+    h, layers = weights.parse_blob(q)
+    deq = weights.build_blob([sp for sp, _, _ in layers], [(w, b) for _, w, b in layers], h["nc"], h["nk"], h["backbone"])
+    fs = [frames.synthetic_frame(i) for i in range(4)]
+    heads = []
+    for b in (q, deq):
+        with YoloEngine(None, (1280, 1024), weights_blob=b, net_size=416, num_slots=4) as e:
+            for s, f in enumerate(fs):
+                e.get_src_image_buffer(s)[:] = f
+            e.submit(0, 4)
+            e.wait()
+            batched = [e.read_head(s).copy() for s in range(4)]
+            single = []
+            for s in range(4):
+                e.detect(s)
+                single.append(e.read_head(s).copy())
+            assert all(np.array_equal(a, c) for a, c in zip(batched, single))
+            heads.append(batched)
+    assert all(np.array_equal(a, c) for a, c in zip(*heads))
+    ho = oracle.Net(q).forward(oracle.preprocess(fs[0], 416))
+    assert heads[0][0].shape == ho.shape == (3549, 86)
+    assert np.abs(heads[0][0] - ho).max() <= HEAD_TOL
+
+
+@pytest.mark.gpu
+def test_engine_refuses_a_grouped_layer_it_has_no_kernel_for(sblob):
+    from irmv_detection_amd import capi
+    from irmv_detection_amd.engine import YoloEngine
+    hdr, layers = weights.parse_blob(sblob)
+    specs = [sp for sp, _, _ in layers]
+    bad = [arch.ConvSpec(sp.name, sp.cin, sp.cout, sp.k, sp.stride, arch.ACT_SILU, sp.groups) if sp.name == "model.2.b1.dw" else sp for sp in specs]
+    blob = weights.build_blob(bad, [(w, b) for _, w, b in layers], hdr["nc"], hdr["nk"], hdr["backbone"])
+    with pytest.raises(capi.IrmvError):
+        YoloEngine(None, (1280, 1024), weights_blob=blob)

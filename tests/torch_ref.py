@@ -1,4 +1,5 @@
-"""Independent torch-CPU statement of the YOLOv8n graph.
+"""Independent torch-CPU statement of the YOLOv8n graph and of its ShuffleNetV2-backbone variant
+(irmv_detection_amd/arch.py BACKBONE_SHUFFLE).
 
 Test infrastructure: used to cross-check oracle/orc_net.c (a different code
 base: F.conv2d / F.max_pool2d / F.interpolate vs hand-written C loops) and by
@@ -15,7 +16,7 @@ from irmv_detection_amd import weights as W
 class TorchNet:
     def __init__(self, blob: bytes, dtype=torch.float32):
         hdr, layers = W.parse_blob(blob)
-        self.nc, self.nk = hdr["nc"], hdr["nk"]
+        self.nc, self.nk, self.backbone = hdr["nc"], hdr["nk"], hdr["backbone"]
         self.p = {}
         for sp, w, b in layers:
             wt = torch.from_numpy(w.astype("float32")).permute(0, 3, 1, 2).contiguous().to(dtype)  # OIHW
@@ -24,8 +25,24 @@ class TorchNet:
 
     def conv(self, name, x):
         sp, w, b = self.p[name]
-        y = F.conv2d(x, w, b, stride=sp.stride, padding=sp.k // 2)
+        y = F.conv2d(x, w, b, stride=sp.stride, padding=sp.k // 2, groups=sp.groups)
         return F.silu(y) if sp.act == 1 else y
+
+    @staticmethod
+    def shuffle(x):
+        """channel shuffle, 2 groups: [a0 .. a(n-1), b0 .. b(n-1)] -> [a0, b0, a1, b1, ...]"""
+        n, c, h, w = x.shape
+        return x.view(n, 2, c // 2, h, w).transpose(1, 2).reshape(n, c, h, w)
+
+    def shuffle_down(self, prefix, x):
+        b1 = self.conv(f"{prefix}.b1.pw", self.conv(f"{prefix}.b1.dw", x))
+        b2 = self.conv(f"{prefix}.b2.pw2", self.conv(f"{prefix}.b2.dw", self.conv(f"{prefix}.b2.pw1", x)))
+        return self.shuffle(torch.cat([b1, b2], 1))
+
+    def shuffle_unit(self, prefix, x):
+        x1, x2 = x.chunk(2, 1)
+        b2 = self.conv(f"{prefix}.b2.pw2", self.conv(f"{prefix}.b2.dw", self.conv(f"{prefix}.b2.pw1", x2)))
+        return self.shuffle(torch.cat([x1, b2], 1))
 
     def c2f(self, prefix, x, n, shortcut):
         y = list(self.conv(f"{prefix}.cv1", x).chunk(2, 1))
@@ -48,13 +65,22 @@ class TorchNet:
         t = self.taps = {}
         t["0"] = a0 = self.conv("model.0.conv", x)
         t["1"] = a1 = self.conv("model.1.conv", a0)
-        t["2"] = a2 = self.c2f("model.2", a1, 1, True)
-        t["3"] = a3 = self.conv("model.3.conv", a2)
-        t["4"] = a4 = self.c2f("model.4", a3, 2, True)
-        t["5"] = a5 = self.conv("model.5.conv", a4)
-        t["6"] = a6 = self.c2f("model.6", a5, 2, True)
-        t["7"] = a7 = self.conv("model.7.conv", a6)
-        t["8"] = a8 = self.c2f("model.8", a7, 1, True)
+        if self.backbone == 1:      # ShuffleNetV2 stages; P3, P4, P5 = blocks 3, 6, 8
+            t["2"] = a2 = self.shuffle_down("model.2", a1)
+            t["3"] = a4 = self.shuffle_unit("model.3", a2)
+            t["4"] = a3 = self.shuffle_down("model.4", a4)
+            t["5"] = a5 = self.shuffle_unit("model.5", a3)
+            t["6"] = a6 = self.shuffle_unit("model.6", a5)
+            t["7"] = a7 = self.shuffle_down("model.7", a6)
+            t["8"] = a8 = self.shuffle_unit("model.8", a7)
+        else:
+            t["2"] = a2 = self.c2f("model.2", a1, 1, True)
+            t["3"] = a3 = self.conv("model.3.conv", a2)
+            t["4"] = a4 = self.c2f("model.4", a3, 2, True)
+            t["5"] = a5 = self.conv("model.5.conv", a4)
+            t["6"] = a6 = self.c2f("model.6", a5, 2, True)
+            t["7"] = a7 = self.conv("model.7.conv", a6)
+            t["8"] = a8 = self.c2f("model.8", a7, 1, True)
         t["9"] = a9 = self.sppf(a8)
         up = lambda z: F.interpolate(z, scale_factor=2, mode="nearest")
         t["12"] = a12 = self.c2f("model.12", torch.cat([up(a9), a6], 1), 1, False)
