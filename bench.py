@@ -75,10 +75,21 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96)
     ap.add_argument("--host-group", type=int, default=32, help="slots per upload group of the host-inclusive leg")
+    # BASELINE configs[4] (not the metric's configuration; the default stays configs[1]/[2]):
+    #   python bench.py --model shufflenet --net 416 --int8
+    ap.add_argument("--model", choices=["yolov8n", "shufflenet"], default="yolov8n")
+    ap.add_argument("--net", type=int, default=640, help="network input size (a multiple of 32)")
+    ap.add_argument("--int8", action="store_true", help="int8 weight blob (per-output-channel scales)")
     return ap.parse_args()
 
 
-def cpu_baseline(blob: bytes, frames_u8, n_frames: int, K, D):
+def make_blob(args):
+    from irmv_detection_amd import arch, weights
+    blob = weights.synthetic_blob(0, backbone=arch.BACKBONE_SHUFFLE if args.model == "shufflenet" else arch.BACKBONE_C2F)
+    return weights.quantize_blob_int8(blob) if args.int8 else blob
+
+
+def cpu_baseline(blob: bytes, frames_u8, n_frames: int, K, D, net_size: int = 640):
     """Oracle pipeline (preprocess -> net -> decode+NMS -> PnP) on the host cores."""
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")     # before libgomp comes up with liboracle.so
     from oracle import oracle
@@ -90,10 +101,10 @@ def cpu_baseline(blob: bytes, frames_u8, n_frames: int, K, D):
     cap = int(os.environ.get("OMP_NUM_THREADS", min(len(os.sched_getaffinity(0)), 16)))
 
     def one_frame(f):
-        x = oracle.preprocess(f, 640)
+        x = oracle.preprocess(f, net_size)
         head = net.forward(x)
-        d = oracle.decode_nms(head, 640, net.nc, net.nk)
-        kp = d["kpts"].reshape(-1, 4, 2) * np.array([f.shape[1] / 640.0, f.shape[0] / 640.0], np.float32)
+        d = oracle.decode_nms(head, net_size, net.nc, net.nk)
+        kp = d["kpts"].reshape(-1, 4, 2) * np.array([f.shape[1] / float(net_size), f.shape[0] / float(net_size)], np.float32)
         for j in range(d["num_dets"]):
             oracle.solve_pnp_ippe(K, D, kp[j], 0)
 
@@ -193,13 +204,14 @@ def main():
     B = args.frames_per_step
 
     # weights: rank 0 generates, everyone receives by ONE broadcast (RCCL over xGMI)
-    blob = weights.synthetic_blob(0) if rank == 0 else None
+    blob = make_blob(args) if rank == 0 else None
+    backbone = arch.BACKBONE_SHUFFLE if args.model == "shufflenet" else arch.BACKBONE_C2F
     if torch is not None:
         wt = D.broadcast_blob(blob, dev)
         torch.cuda.synchronize()
-        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=B)
+        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=B, net_size=args.net)
     else:
-        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=B)
+        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=B, net_size=args.net)
 
     # this rank's frames: round-robin over the global frame index, made resident in HBM once
     my = D.shard_frames(B * world, rank, world)
@@ -295,7 +307,8 @@ def main():
         traffic = None
         import re
         base_name = re.sub(r"_i\d+", "", dom_name)
-        for tname in ("r02_traffic.json", "r01_traffic.json"):
+        default_cfg = (args.model, args.net, args.int8, B) == ("yolov8n", 640, False, 128)   # what the counter files were collected on
+        for tname in (("r02_traffic.json", "r01_traffic.json") if default_cfg else ()):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 with open(tpath) as tf:
@@ -304,7 +317,7 @@ def main():
         # in-kernel MFMA utilisation of the conv kernels from the separate rocprofv3 --pmc pass (scripts/collect_mfma.py)
         mfma = None
         mpath = os.path.join(ROOT, "profiles", "r02_mfma.json")
-        if os.path.exists(mpath):
+        if default_cfg and os.path.exists(mpath):
             with open(mpath) as mf:
                 mfma = json.load(mf)
         if ai >= ridge:
@@ -344,11 +357,13 @@ def main():
             "value": round(fps, 1), "value_hbm_resident": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"synthetic {sw}x{sh} u8 camera frames resident in HBM -> 640x640 YOLOv8n "
-                                   f"(nc=14, 4-kpt head, seeded weights) -> decode+NMS -> IPPE PnP; "
-                                   f"{B} independent frames per step per GPU as {eng.num_streams} concurrently replayed hipGraphs (BASELINE configs[1]/[2])",
-                       "frames_per_step_per_gpu": B, "streams_per_gpu": eng.num_streams, "src": f"{sw}x{sh}", "net": 640, "parallelism": f"dp{world} (replicas, frames sharded)",
-                       "gflop_per_frame": round(arch.flops_per_frame() / 1e9, 3), "detections_last_step_rank0": n_dets},
+            "config": {"workload": f"synthetic {sw}x{sh} u8 camera frames resident in HBM -> {args.net}x{args.net} "
+                                   + ("YOLOv8n" if args.model == "yolov8n" else "YOLOv8n with ShuffleNetV2 backbone stages") +
+                                   f" (nc=14, 4-kpt head, seeded {'int8' if args.int8 else 'fp16'} weights) -> decode+NMS -> IPPE PnP; "
+                                   f"{B} independent frames per step per GPU as {eng.num_streams} concurrently replayed hipGraphs "
+                                   + ("(BASELINE configs[1]/[2])" if (args.model, args.net, args.int8) == ("yolov8n", 640, False) else "(BASELINE configs[4] family; NOT the configuration the metric is quoted on)"),
+                       "frames_per_step_per_gpu": B, "streams_per_gpu": eng.num_streams, "src": f"{sw}x{sh}", "net": args.net, "parallelism": f"dp{world} (replicas, frames sharded)",
+                       "gflop_per_frame": round(arch.flops_per_frame(args.net, backbone=backbone) / 1e9, 3), "detections_last_step_rank0": n_dets},
             "roofline": roofline,
         }
         out.update(extra)
@@ -357,9 +372,9 @@ def main():
         # Latency legs on an engine shaped like the reference node's: three slots = the TripleBuffer (src/irm_detector.cpp:
         # 35-38, 68-72), a compute stream per slot.  (A second engine in the process: safe since the round-2 teardown fix.)
         if torch is not None:
-            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=3)
+            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=3, net_size=args.net)
         else:
-            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=3)
+            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=3, net_size=args.net)
         for s3 in range(3):
             leng.get_src_image_buffer(s3)[:] = frames_u8[s3 % len(frames_u8)]
         # single-frame latency, host frame -> host detections (the reference's detect(), PCIe inclusive)
@@ -412,8 +427,8 @@ def main():
     if out is not None:
         out.update(late)
         if world == 1 and not args.no_cpu_baseline:      # last: nothing GPU-side is timed while the host cores are busy
-            out["cpu_baseline"] = cpu_baseline(weights.synthetic_blob(0), frames_u8, args.cpu_frames,
-                                               np.array(DEFAULT_CAMERA_MATRIX), np.array(DEFAULT_DIST_COEFFS))
+            out["cpu_baseline"] = cpu_baseline(make_blob(args), frames_u8, args.cpu_frames,
+                                               np.array(DEFAULT_CAMERA_MATRIX), np.array(DEFAULT_DIST_COEFFS), args.net)
     D.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -126,17 +126,20 @@ def convert(onnx_bytes: bytes) -> bytes:
     nk = int(wk.shape[0]) if wk is not None else 0
     if nk not in (0, 8):
         raise ValueError(f"keypoint head has {nk} outputs; this engine supports 4 keypoints x (x, y) = 8")
-    specs = arch.conv_specs(nc, nk)
+    # the ShuffleNetV2-backbone variant (arch.BACKBONE_SHUFFLE) is recognised by its first depthwise conv; its layer names
+    # are this build's (the external repository the reference's README points to is not available offline)
+    backbone = arch.BACKBONE_SHUFFLE if _lookup(init, "model.2.b1.dw")[0] is not None else arch.BACKBONE_C2F
+    specs = arch.conv_specs(nc, nk, backbone)
     tensors = []
     for sp in specs:
         w, b = _lookup(init, sp.name)
         if w is None:
             raise ValueError(f"initializers of {sp.name} not found")
         if tuple(w.shape) != (sp.cout, sp.cin, sp.k, sp.k) or b.shape != (sp.cout,):
-            raise ValueError(f"{sp.name}: shape {tuple(w.shape)} does not match YOLOv8n ({sp.cout}, {sp.cin}, {sp.k}, {sp.k})")
+            raise ValueError(f"{sp.name}: shape {tuple(w.shape)} does not match the layer table ({sp.cout}, {sp.cin}, {sp.k}, {sp.k})")
         tensors.append((np.ascontiguousarray(w.astype(np.float32).transpose(0, 2, 3, 1)).astype(np.float16),   # OIHW -> OHWI
                         np.ascontiguousarray(b.astype(np.float32))))
-    return weights.build_blob(specs, tensors, nc, nk)
+    return weights.build_blob(specs, tensors, nc, nk, backbone)
 
 
 # ---- minimal writer, used by the tests to make an ONNX file to import -------------

@@ -31,7 +31,7 @@ def test_class_table_matches_reference_enum():
 
 def test_blob_roundtrip_and_determinism(blob):
     hdr, layers = weights.parse_blob(blob)
-    assert hdr == dict(nc=14, nk=8, reg_max=16, n_layers=72, dtype=weights.DTYPE_FP16)
+    assert hdr == dict(nc=14, nk=8, reg_max=16, n_layers=72, dtype=weights.DTYPE_FP16, backbone=0)
     specs, tensors = weights.synthetic_tensors(0)
     for (sp, w, b), sp2, (w2, b2) in zip(layers, specs, tensors):
         assert sp == sp2 and np.array_equal(w, w2) and np.array_equal(b, b2)

@@ -43,3 +43,11 @@ def test_cli_writes_sibling_irmw(tmp_path, blob):
     p.write_bytes(_as_onnx(specs, tensors))
     assert onnx_import.main(["prog", str(p)]) == 0
     assert (tmp_path / "yolov7.irmw").read_bytes() == blob
+
+
+def test_shuffle_backbone_is_recognised_and_round_trips():
+    from irmv_detection_amd import arch
+    specs, tensors = weights.synthetic_tensors(0, backbone=arch.BACKBONE_SHUFFLE)
+    out = onnx_import.convert(_as_onnx(specs, tensors))
+    assert out == weights.synthetic_blob(0, backbone=arch.BACKBONE_SHUFFLE)
+    assert weights.parse_blob(out)[0]["backbone"] == arch.BACKBONE_SHUFFLE
