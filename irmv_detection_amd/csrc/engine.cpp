@@ -184,6 +184,7 @@ struct irmv_engine {
     irmv_engine_cfg cfg{};
     int nc = 0, nk = 0, A = 0, no = 0;
     int backbone = 0;   // 0: C2f stages (YOLOv8n), 1: ShuffleNetV2 stages (blob header)
+    bool xcd_order = false;   // conv kernels walk their workgroup lists XCD-contiguously (IRMV_XCD)
     int lvl_hw[3] = {0, 0, 0}, lvl_base[3] = {0, 0, 0};
     size_t frame_bytes = 0;
     hipStream_t stream = nullptr;                 // stream 0: single-slot detect(), read-backs, profile
@@ -669,6 +670,7 @@ static int build_engine(irmv_engine *e)
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->h2d_stream, hipStreamNonBlocking));
     { const char *ic = getenv("IRMV_INLINE_COPIES"); e->inline_copies = ic && ic[0] == '1'; }
+    { const char *xo = getenv("IRMV_XCD"); e->xcd_order = xo && xo[0] == '1'; }
     e->slot_owner.assign(S, nullptr);
     e->frame_bytes = (size_t)c.src_width * c.src_height * 3;
     HIP_TRY(hipHostMalloc((void **)&e->src_host, e->frame_bytes * S, hipHostMallocDefault));
@@ -1407,6 +1409,7 @@ static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int co
         cs.shift = s.shift;
         return cs;
     };
+    a.xcd = e->xcd_order ? 1 : 0;
     a.s0 = seg(op.s0);
     a.s1 = seg(op.s1);
     a.Hin = op.Hin; a.Win = op.Win; a.Hout = op.Hout; a.Wout = op.Wout;

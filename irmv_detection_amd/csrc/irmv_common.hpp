@@ -145,6 +145,7 @@ struct ConvArgs {
     const float *bias2;
     float *out2;
     int out2_ld, n2;
+    int xcd;            // 1: XCD-aware workgroup order (k_conv.hip xcd_order)
 };
 
 struct ConvCfg {

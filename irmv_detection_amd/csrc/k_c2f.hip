@@ -25,6 +25,15 @@ constexpr int HP = 32;                    // bytes per pixel of the 16-channel p
                                           // 16 distinct 16-byte slots of a 256-byte window: conflict-free ds_read_b128)
 
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// Global-memory B fragments are loaded UNCONDITIONALLY from a clamped (always valid) address and zeroed by a select
+// afterwards, as four dwords: behind `if (inside) B = load` the compiler builds the zero / loaded merge per 16-bit
+// element and waits for every load where it is issued (vmcnt(0) after each pair), which serialises the round trips the
+// prefetch below is there to overlap.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ld16(const half_t *p) { return *reinterpret_cast<const u32x4 *>(p); }
+__device__ __forceinline__ u32x4 keep_if(bool c, u32x4 v) { return c ? v : (u32x4){0u, 0u, 0u, 0u}; }
+__device__ __forceinline__ half8 as_h8(u32x4 v) { return __builtin_bit_cast(half8, v); }
 }  // namespace
 
 __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
@@ -41,7 +50,8 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
     const int S = a.S;
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 
-    // ---- weights (16 fragments) into registers; the loads overlap the input staging ----
+    // ---- weights (16 fragments) into registers, each a phase or more before its first use: cv1 and m.0.cv1 now (the loads
+    // overlap the input loads), m.0.cv2 and cv2 behind the first barrier.  All sixteen from the start cost a wave per SIMD.
     const half8 *w;
     w = reinterpret_cast<const half8 *>(a.w_cv1) + lane;
     const half8 Wc1[2] = {w[0], w[64]};
@@ -49,34 +59,44 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
     w = reinterpret_cast<const half8 *>(a.w_m1) + lane;
 #pragma unroll
     for (int ks = 0; ks < 5; ks++) Wm1[ks] = w[ks * 64];
-    w = reinterpret_cast<const half8 *>(a.w_m2) + lane;
+    // biases: cv1's into registers with the weights; the later layers' -> LDS (visible after the first barrier).  Fetched
+    // from global memory at the start of its phase each would expose a memory round trip behind a barrier.
+    float bias_c1[8];
 #pragma unroll
-    for (int ks = 0; ks < 5; ks++) Wm2[ks] = w[ks * 64];
-    w = reinterpret_cast<const half8 *>(a.w_cv2) + lane;
-    const half8 Wc2[2][2] = {{w[0], w[64]}, {w[128], w[192]}};   // [tile][k-step]
+    for (int i = 0; i < 8; i++) bias_c1[i] = a.b_cv1[g * 8 + i];
+    __shared__ float s_bias[16 + 16 + 32];
+    if (tid < 16) { s_bias[tid] = a.b_m1[tid]; s_bias[16 + tid] = a.b_m2[tid]; }
+    else if (tid < 48) s_bias[16 + tid] = a.b_cv2[tid - 16];
 
     // ---- 1: cv1 (1x1, 32 -> 32, SiLU) on the 20 x 20 region -> y0 (centre only), y1 (whole region) ----
     {
-        float bias[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) bias[i] = a.b_cv1[g * 8 + i];
+        const float (&bias)[8] = bias_c1;
         const half_t *xin = a.x + (size_t)b * S * S * a.x_ld;
-        for (int t = wave; t < XN / 16; t += 4) {
+        // the block input is read exactly once per workgroup, so its B fragments come straight from memory (zero outside
+        // the image) -- ALL of this wave's tiles at once: loaded tile by tile, each of the 6 - 7 tiles exposed its own
+        // memory round trip
+        constexpr int NT1 = (XN / 16 + 3) / 4;
+        u32x4 Bq[NT1];
+#pragma unroll
+        for (int i = 0; i < NT1; i++) {
+            const int t = wave + 4 * i;
+            const int m = (t < XN / 16 ? t : 0) * 16 + r;
+            const int ly = m / XW, lx = m - ly * XW;
+            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+            const bool in = t < XN / 16 && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S;
+            Bq[i] = ld16(xin + ((size_t)(in ? gy : 0) * S + (in ? gx : 0)) * a.x_ld + g * 8);   // zeroed (keep_if) where it is used: the select waits for the load
+        }
+#pragma unroll
+        for (int i = 0; i < NT1; i++) {
+            const int t = wave + 4 * i;
+            if (t >= XN / 16) break;
             const int m = t * 16 + r;
-            // the block input is read exactly once per workgroup, so its B fragments come straight from memory (zero
-            // outside the image)
-            half8 B = zero8;
-            {
-                const int ly = m / XW, lx = m - ly * XW;
-                const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-                if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S)
-                    B = *reinterpret_cast<const half8 *>(xin + ((size_t)gy * S + gx) * a.x_ld + g * 8);
-            }
+            const int ly = m / XW, lx = m - ly * XW;
+            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+            const half8 B = as_h8(keep_if((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S, Bq[i]));
             f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[0], B, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[1], B, acc1, 0, 0, 0);
-            const int ly = m / XW, lx = m - ly * XW;
-            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
             half8 o = zero8;   // outside the image y1 is the bottleneck's zero padding
             if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S) {
 #pragma unroll
@@ -94,11 +114,17 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
     }
     __syncthreads();
 
+    w = reinterpret_cast<const half8 *>(a.w_m2) + lane;
+#pragma unroll
+    for (int ks = 0; ks < 5; ks++) Wm2[ks] = w[ks * 64];
+    w = reinterpret_cast<const half8 *>(a.w_cv2) + lane;
+    const half8 Wc2[2][2] = {{w[0], w[64]}, {w[128], w[192]}};   // [tile][k-step]
+
     // ---- 2: m.0.cv1 (3x3, 16 -> 16, SiLU) on the 18 x 18 region; Cin = 16: one k-step spans two taps ----
     {
         float bias[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) bias[i] = a.b_m1[g * 4 + i];
+        for (int i = 0; i < 4; i++) bias[i] = s_bias[g * 4 + i];
         int toff[5];   // byte offset of this lane's tap / channel half inside y1, relative to the pixel (-1 = no tap)
 #pragma unroll
         for (int ks = 0; ks < 5; ks++) {
@@ -135,7 +161,7 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
     {
         float bias[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) bias[i] = a.b_m2[g * 4 + i];
+        for (int i = 0; i < 4; i++) bias[i] = s_bias[16 + g * 4 + i];
         int toff[5];
 #pragma unroll
         for (int ks = 0; ks < 5; ks++) {
@@ -171,7 +197,7 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
     {
         float bias[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) bias[i] = a.b_cv2[g * 8 + i];
+        for (int i = 0; i < 8; i++) bias[i] = s_bias[32 + g * 8 + i];
         half_t *out = a.out + (size_t)b * S * S * a.out_ld;
         for (int t = wave; t < T * T / 16; t += 4) {
             const int m = t * 16 + r;
@@ -265,12 +291,19 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
     const int H = a.H, W = a.W;
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
     half_t *cat = a.cat + (size_t)b * H * W * a.cat_ld;   // the block's concat buffer [H][W][cat_ld]: y0 | y1 | y2 [| y3]
+    // biases of the later phases -> LDS now (visible after the first barrier): fetched from global memory at the start of
+    // its phase each would expose a memory round trip right behind a barrier
+    __shared__ float s_bias[32 + 32 + 64];
+    if (tid < 32) { s_bias[tid] = a.b_m1[tid]; s_bias[32 + tid] = a.b_m2[tid]; }
+    if (MODE != 1 && tid < 64) s_bias[64 + tid] = a.b_cv2[tid];
 #if IRMV_EXP & 4
     long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = clock64();
     long long t_prev = t_begin;
 #endif
 
+    u32x4 Y01[2][2];   // mode B only
+    static_assert(R3N / 16 == 8, "two output tiles per wave");
     if constexpr (MODE != 2) {
         // ---- 1: cv1 (1x1, Cin -> 64 = y0 | y1, SiLU) on the 12 x 20 region, B fragments straight from memory ----
         half8 W1[4][KS1];
@@ -289,7 +322,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
         const int H0 = H >> a.s0.shift, W0 = W >> a.s0.shift, H1 = H >> a.s1.shift, W1s = W >> a.s1.shift;
         // the block input is read once per workgroup, straight into B fragments; the next tile's loads are in flight under
         // this tile's MFMAs and SiLU epilogue (a wave walks ~4 tiles: without this each would expose a full memory round trip)
-        auto load_tile = [&](int t, half8 (&B)[KS1]) {
+        auto load_tile = [&](int t, u32x4 (&B)[KS1]) {
             const int m = t * 16 + r;
             const int ly = m / R1W, lx = m - ly * R1W;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
@@ -300,11 +333,10 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) {
                 const int c = ks * 32 + 8 * g;
-                B[ks] = zero8;
-                if (inside && !(IRMV_ABL & 1)) B[ks] = *reinterpret_cast<const half8 *>(c < a.s0.C ? p0 + c : p1 + (c - a.s0.C));
+                B[ks] = ld16(c < a.s0.C ? p0 + c : p1 + (c - a.s0.C));   // clamped address: always valid; zeroed (keep_if) where it is USED
             }
         };
-        half8 Bn[KS1];
+        u32x4 Bn[KS1];
         load_tile(wave, Bn);
         for (int t = wave; t < R1N / 16; t += 4) {
             const int m = t * 16 + r;
@@ -313,7 +345,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             half8 B[KS1];
 #pragma unroll
-            for (int ks = 0; ks < KS1; ks++) B[ks] = Bn[ks];
+            for (int ks = 0; ks < KS1; ks++) B[ks] = as_h8(keep_if(inside, Bn[ks]));   // the select waits for the load: here, not at issue
             if (t + 4 < R1N / 16) load_tile(t + 4, Bn);
             f32x4 acc[4];
 #pragma unroll
@@ -347,23 +379,38 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             }
         }
     } else {
+        // y0, y1 of this wave's two output tiles (operands of cv2, phase 4) are fetched NOW: they depend on nothing this
+        // kernel computes, and loaded where they are used each tile exposed a memory round trip
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int m = (wave + 4 * i) * 16 + r;
+            const int ly = m / FW, lx = m - ly * FW;
+            const int gy = oy0 + ly, gx = ox0 + lx;
+            const bool in = gy < H && gx < W;
+            const half_t *q = cat + ((size_t)(in ? gy : 0) * W + (in ? gx : 0)) * a.cat_ld + g * 8;
+            Y01[i][0] = ld16(q);          // zeroed (keep_if) in phase 4
+            Y01[i][1] = ld16(q + 32);
+        }
         // ---- 1': the previous bottleneck's output (slice y_prev of the concat buffer) with a 2-pixel halo -> LDS ----
         const half_t *src = cat + a.prev_coff;
         constexpr int NP = (R1N * 4 + 255) / 256;   // 16-byte pieces per thread: all loads issued before the first LDS store
-        half8 v[NP];
+        u32x4 v[NP];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const int e = tid + i * 256;
             const int m = e >> 2, q = e & 3;
             const int ly = m / R1W, lx = m - ly * R1W;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            v[i] = zero8;
-            if (e < R1N * 4 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v[i] = *reinterpret_cast<const half8 *>(src + ((size_t)gy * W + gx) * a.cat_ld + q * 8);
+            const bool in = e < R1N * 4 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            v[i] = ld16(src + ((size_t)(in ? gy : 0) * W + (in ? gx : 0)) * a.cat_ld + q * 8);
         }
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const int e = tid + i * 256;
-            if (e < R1N * 4) *reinterpret_cast<half8 *>(s_in + (e >> 2) * PS + (e & 3) * 16) = v[i];
+            const int m = e >> 2;
+            const int ly = m / R1W, lx = m - ly * R1W;
+            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+            if (e < R1N * 4) *reinterpret_cast<u32x4 *>(s_in + m * PS + (e & 3) * 16) = keep_if((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W, v[i]);
         }
     }
     C2F_STAMP(0);
@@ -380,7 +427,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             for (int tap = 0; tap < 9; tap++) Wm[nt][tap] = w[(size_t)(nt * 9 + tap) * 64];
         float bias[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) bias[i] = a.b_m1[g * 8 + i];
+        for (int i = 0; i < 8; i++) bias[i] = s_bias[g * 8 + i];
         for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : (R2N + 15) / 16); t += 4) {
             const int m = t * 16 + r;
             const bool mv = m < R2N;
@@ -422,7 +469,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             for (int tap = 0; tap < 9; tap++) Wm[nt][tap] = w[(size_t)(nt * 9 + tap) * 64];
         float bias[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) bias[i] = a.b_m2[g * 8 + i];
+        for (int i = 0; i < 8; i++) bias[i] = s_bias[32 + g * 8 + i];
         for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : R3N / 16); t += 4) {
             const int m = t * 16 + r;
             const int ly = m / FW, lx = m - ly * FW;
@@ -470,7 +517,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int i = 0; i < 8; i++) bias[u * 8 + i] = a.b_cv2[u * 32 + g * 8 + i];
+            for (int i = 0; i < 8; i++) bias[u * 8 + i] = s_bias[64 + u * 32 + g * 8 + i];
         half_t *out = a.out + (size_t)b * H * W * a.out_ld;
         for (int t = wave; t < ((IRMV_ABL & 4) ? 0 : R3N / 16); t += 4) {
             const int m = t * 16 + r;
@@ -483,13 +530,9 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
                 B[1] = *reinterpret_cast<const half8 *>(s_in + ((ly + 2) * R1W + lx + 2) * PS + g * 16);
                 B[2] = *reinterpret_cast<const half8 *>(s_yn + m * PS + g * 16);
             } else {
-                // y0, y1 are read once per pixel: straight from the concat buffer; y2 = the staged slice; y3 = this kernel's
-                B[0] = zero8; B[1] = zero8;
-                if (inside) {
-                    const half_t *q = cat + ((size_t)gy * W + gx) * a.cat_ld + g * 8;
-                    B[0] = *reinterpret_cast<const half8 *>(q);
-                    B[1] = *reinterpret_cast<const half8 *>(q + 32);
-                }
+                // y0, y1 are read once per pixel: straight from the concat buffer (at kernel start); y2 = the staged slice; y3 = this kernel's
+                B[0] = as_h8(keep_if(inside, Y01[(t - wave) >> 2][0]));
+                B[1] = as_h8(keep_if(inside, Y01[(t - wave) >> 2][1]));
                 B[2] = *reinterpret_cast<const half8 *>(s_in + ((ly + 2) * R1W + lx + 2) * PS + g * 16);
                 B[3] = *reinterpret_cast<const half8 *>(s_yn + m * PS + g * 16);
             }

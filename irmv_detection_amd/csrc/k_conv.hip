@@ -32,6 +32,16 @@ struct DeepPrefetchDepth { static constexpr int value = (MT + NT <= 2) ? 12 : ((
 
 // CT: walk K chunk-major -- k-step s = (32-channel chunk s / 9, tap s % 9), the order of the LDS-staged family below -- with
 // weights in that family's nt = 1 packing, so a 3x3 layer of the LDS family can run on this kernel bit-identically.
+// XCD-aware workgroup order (cdna_hip_programming.md T1): workgroup ids are dealt round-robin to the 8 XCDs, each with its
+// own L2.  `xcd_order` turns the id into a position in a list of which every XCD walks one CONTIGUOUS eighth -- with the
+// lists below ordered image-major, an XCD works on the same images in every layer, so a layer reads what the previous one
+// left in that XCD's L2.  Bijective for any grid size; purely a placement choice (results cannot depend on it).
+__device__ __forceinline__ int xcd_order(int lin, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, x = lin & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+}
+
 template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32, bool CT = false, bool DEEP = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 {
@@ -40,8 +50,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     static_assert(!CT || (KS == 3 && !CIN16), "chunk-major order is the 3x3 LDS family's");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
-    const int tile0 = (blockIdx.x * 4 + wave) * MT;
-    const int nt0 = blockIdx.y * NT;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.xcd) {   // list order: pixel block major (= image major), then output-channel block
+        const int L = xcd_order(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+        bx = L / (int)gridDim.y;
+        by = L - bx * (int)gridDim.y;
+    }
+    const int tile0 = (bx * 4 + wave) * MT;
+    const int nt0 = by * NT;
     const int HWo = a.Hout * a.Wout;
 
     int iy0[MT], ix0[MT], bb[MT], mm[MT];
@@ -520,9 +536,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
     //            of staging full-width rows.
     // A workgroup keeps its tile position for `ipw` consecutive images: the staging plan below is computed once,
     // and the load -> LDS -> MFMA pipeline runs through all (image, chunk) steps without draining.
-    const int grp = blockIdx.x / (tiles_x * tiles_y), tile = blockIdx.x - grp * (tiles_x * tiles_y);
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.xcd) {   // list order: image group, then output-channel block, then tile
+        const int tiles = tiles_x * tiles_y, nby = gridDim.y;
+        const int L = xcd_order(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * nby);
+        const int g_ = L / (tiles * nby), rem = L - g_ * (tiles * nby);
+        by = rem / tiles;
+        bx = g_ * tiles + (rem - by * tiles);
+    }
+    const int grp = bx / (tiles_x * tiles_y), tile = bx - grp * (tiles_x * tiles_y);
     const int img = grp * ipw, nimg = min(ipw, batch - img);
-    const int nblk = blockIdx.y;
+    const int nblk = by;
     const int HWo = a.Hout * a.Wout;
     int PW, PR, iy_base, ix_base;
     int poff[MT], mloc[MT];
@@ -567,9 +591,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
     float *s_bias2 = s_bias + 64;
     half8 *s_w2 = reinterpret_cast<half8 *>(s_bias + 128);
     if constexpr (NT % 2 == 0) {
-        if (tid < NT * 16) s_bias[tid] = a.bias[blockIdx.y * NT * 16 + tid];
+        if (tid < NT * 16) s_bias[tid] = a.bias[by * NT * 16 + tid];
     } else {   // one tile: s_bias[4 g + i] = bias of the channel lane group g holds in register i
-        const int t = blockIdx.y;
+        const int t = by;
         if (tid < 16) s_bias[tid] = a.bias[a.pair ? ((t >> 1) * 32 + (tid >> 2) * 8 + (t & 1) * 4 + (tid & 3)) : (t * 16 + tid)];
     }
     if constexpr (N2 > 0) {

@@ -34,7 +34,7 @@ constexpr int MTC = TY / 4;                          // model.1 output rows per 
 constexpr int INP = INW + 1;                         // row pitch (pixels); the extra column stays zero
 }  // namespace
 
-__global__ __launch_bounds__(256) void front_kernel(FrontArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void front_kernel(FrontArgs a)   // 5 waves per SIMD = 96 VGPRs: the occupancy step the kernel sat on before its biases moved to LDS
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // a.stage_bytes: source region, later model.0's tile
     __shared__ __attribute__((aligned(16))) half4 s_in[INH * INP];
@@ -46,6 +46,13 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs a)
     const int oy0 = tyi * TY, ox0 = txi * TX;
     const int net = a.net, W0 = net >> 1, W1 = net >> 2;
     const int gy0 = 4 * oy0 - 3, gx0 = 4 * ox0 - 3;   // net-input coordinates of s_in[0][0]
+
+    // both biases -> LDS now (visible after the staging barrier): fetched from global memory where they are used (start of
+    // stage B, epilogue of stage C) each exposes a memory round trip of a ~10 us workgroup; held in registers from here
+    // they cost the occupancy step this kernel sits on (measured +10 %)
+    __shared__ float s_bias[16 + 32];
+    if (tid < 16) s_bias[tid] = a.b0[tid];
+    else if (tid < 48) s_bias[tid] = a.b1[tid - 16];
 
     // model.1 weights (5 k-steps x 2 tiles) and model.0 weights (2 k-steps) into registers early
     half8 A1[5][2];
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs a)
         const half4 z4 = (half4){0, 0, 0, 0};
         float bias0[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) bias0[i] = a.b0[g * 4 + i];
+        for (int i = 0; i < 4; i++) bias0[i] = s_bias[g * 4 + i];
         for (int t = wave; t < NTILES; t += 4) {
             const int m = t * 16 + r;
             const bool mv = m < NPX;
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs a)
         if (ox < W1) {
             float bias1[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) bias1[i] = a.b1[g * 8 + i];
+            for (int i = 0; i < 8; i++) bias1[i] = s_bias[16 + g * 8 + i];
 #pragma unroll
             for (int mt = 0; mt < MTC; mt++) {
                 const int oy = oy0 + MTC * wave + mt;

@@ -27,6 +27,11 @@ layers)  SLOTS=64 run layers64 300 python3 scripts/prof_layers.py
 bench)   run bench 600 python3 bench.py ;;
 benchhost) for g in 16 32 64; do IRMV_BENCH_SKIP=latency run benchhost_$g 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --host-group $g; done ;;
 bench2)  IRMV_DIST_BACKEND=gloo IRMV_FORCE_DEVICE=0 run bench2 500 python3 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --frames-per-step 32 ;;
+xcdab)   export IRMV_TUNE_CACHE=$O/tc_xcd.txt; rm -f $IRMV_TUNE_CACHE     # A/B of the XCD-aware workgroup order, one tile table
+         IRMV_XCD=0 SLOTS=64 run layers64_x0 300 python3 scripts/prof_layers.py
+         IRMV_XCD=1 SLOTS=64 run layers64_x1 300 python3 scripts/prof_layers.py
+         IRMV_XCD=0 SLOTS=64 run layers64_x0b 300 python3 scripts/prof_layers.py
+         unset IRMV_TUNE_CACHE ;;
 bench4)  run bench4 600 python3 bench.py --model shufflenet --net 416 --int8 --steps 100 --warmup 10   # BASELINE configs[4]
          grep '^{' $O/bench4.log | tail -1 > $O/bench4.json ;;
 benchq)  run benchq 400 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline ;;
