@@ -113,7 +113,8 @@ _lib = None
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    """The in-tree library; IRMV_LIB_PATH names another build of it (A/B runs of two kernel versions on one box)."""
+    return os.environ.get("IRMV_LIB_PATH") or _build.LIB_PATH
 
 
 def load():

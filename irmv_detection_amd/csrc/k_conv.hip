@@ -111,33 +111,42 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                 p1[mt] = a.s1.p + ((size_t)(bb[mt] * H1 + (iyc >> a.s1.shift)) * W1 + (ixc >> a.s1.shift)) * a.s1.ld;
         }
     };
-    half8 Ab[PF][NT], Bb[PF][MT];
-    auto load_step = [&](half8 (&A)[NT], half8 (&B)[MT]) {
-        if (l_ks < a.ksteps) {
-            if constexpr (CIN16) {
-                // Cin == 16: one k-step of 32 spans TWO filter taps (lanes g<2: tap 2i, g>=2: tap 2i+1)
-                set_tap(2 * l_ks + (g >> 1));
-                const int c = 8 * (g & 1);
+    // Every load of the ring is UNCONDITIONAL: from a clamped, always valid address (set_tap: pixel (0, 0) of the image for
+    // taps in the padding and for rows past M; the last 8 channels for K positions past Cin; the last k-step again past
+    // the end), as four dwords.  What must be zero (padding taps of a 3x3; K positions past Cin) is zeroed by a select
+    // where the fragment is USED.  Behind `if (valid) B = load` each load sits in its own branch, the compiler can no
+    // longer count the loads in flight and every wait becomes vmcnt(0): the prefetch ring below then waits, at each
+    // k-step, for the loads it has just issued -- one exposed memory round trip per k-step.
+    // 1x1 convs need no select at all: there is no padding, a row past M fills a B column whose results are never stored,
+    // and K positions past Cin meet zero weights (pack_conv) with finite activations.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    half8 Ab[PF][NT];
+    u32x4 Bb[PF][MT];
+    bool Bz[PF][MT];   // fragment must read as zero
+    auto load_step = [&](half8 (&A)[NT], u32x4 (&B)[MT], bool (&Z)[MT]) {
+        const int ks = l_ks < a.ksteps ? l_ks : a.ksteps - 1;
+        if constexpr (CIN16) {
+            // Cin == 16: one k-step of 32 spans TWO filter taps (lanes g<2: tap 2i, g>=2: tap 2i+1)
+            set_tap(2 * ks + (g >> 1));
+            const int c = 8 * (g & 1);
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    B[mt] = zero8;
-                    if (pv[mt]) B[mt] = *reinterpret_cast<const half8 *>(p0[mt] + c);
-                }
-            } else {
-                if constexpr (CT) { set_tap(l_ks % 9); l_cc = (l_ks / 9) * 32; }
-                const int c = l_cc + 8 * g;
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    B[mt] = zero8;
-                    if (pv[mt] && c < a.Cin) {
-                        const half_t *q = (c < a.s0.C) ? (p0[mt] + c) : (p1[mt] + (c - a.s0.C));
-                        B[mt] = *reinterpret_cast<const half8 *>(q);
-                    }
-                }
+            for (int mt = 0; mt < MT; mt++) {
+                B[mt] = *reinterpret_cast<const u32x4 *>(p0[mt] + c);
+                Z[mt] = !pv[mt];
             }
+        } else {
+            if constexpr (CT) { set_tap(ks % 9); l_cc = (ks / 9) * 32; }
+            const int c = l_cc + 8 * g;
+            const int cs = c < a.Cin ? c : a.Cin - 8;
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) A[nt] = wp[(size_t)(nt * a.ksteps + l_ks) * 64];
+            for (int mt = 0; mt < MT; mt++) {
+                const half_t *q = (cs < a.s0.C) ? (p0[mt] + cs) : (p1[mt] + (cs - a.s0.C));
+                B[mt] = *reinterpret_cast<const u32x4 *>(q);
+                Z[mt] = !(pv[mt] && c < a.Cin);
+            }
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) A[nt] = wp[(size_t)(nt * a.ksteps + ks) * 64];
         // advance
         l_ks++;
         if constexpr (!CIN16 && !CT) {
@@ -152,20 +161,30 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 
     if constexpr (!CIN16 && !CT) set_tap(0);
 #pragma unroll
-    for (int i = 0; i < PF; i++) load_step(Ab[i], Bb[i]);
-    for (int s = 0; s < a.ksteps; s += PF) {
+    for (int i = 0; i < PF; i++) load_step(Ab[i], Bb[i], Bz[i]);
+    auto mma_slot = [&](int i) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const u32x4 bq = (KS == 1) ? Bb[i][mt] : (Bz[i][mt] ? (u32x4){0u, 0u, 0u, 0u} : Bb[i][mt]);
+            const half8 bf = __builtin_bit_cast(half8, bq);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab[i][nt], bf, acc[mt][nt], 0, 0, 0);
+        }
+    };
+    // whole rounds of the ring without a branch (a branch around a load makes the wait counts conservative again), then
+    // the remainder
+    int s = 0;
+    for (; s + PF <= a.ksteps; s += PF) {
 #pragma unroll
         for (int i = 0; i < PF; i++) {
-            if (s + i < a.ksteps) {
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int nt = 0; nt < NT; nt++)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab[i][nt], Bb[i][mt], acc[mt][nt], 0, 0, 0);
-                load_step(Ab[i], Bb[i]);
-            }
+            mma_slot(i);
+            load_step(Ab[i], Bb[i], Bz[i]);
         }
     }
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+        if (s + i < a.ksteps) mma_slot(i);
 
     // ---- epilogue: bias, SiLU, shortcut, convert, NHWC store ----
     // D layout of 16x16x32: col = lane & 15 (pixel), row = (lane >> 4) * 4 + reg (cout row of the tile).
@@ -375,9 +394,13 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
     const int nblk = blockIdx.y;
+    // weights -> LDS: every piece of a thread is loaded before the first is stored (NT * KS * 64 / 256 = KS pieces; a
+    // load -> store loop serialises KS memory round trips at the head of every workgroup)
+    half8 wreg[KS];
     {
         const half8 *wsrc = reinterpret_cast<const half8 *>(a.w) + (size_t)nblk * NT * KS * 64;
-        for (int e = tid; e < NT * KS * 64; e += 256) s_w[e] = wsrc[e];
+#pragma unroll
+        for (int i = 0; i < KS; i++) wreg[i] = wsrc[tid + i * 256];
     }
     const int HWo = a.Hout * a.Wout;
     const int H0 = a.Hin >> a.s0.shift, W0 = a.Win >> a.s0.shift, H1 = a.Hin >> a.s1.shift, W1 = a.Win >> a.s1.shift;
@@ -403,9 +426,12 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
             p1[mt] = a.s1.p + ((size_t)(b * H1 + (oy >> a.s1.shift)) * W1 + (ox >> a.s1.shift)) * a.s1.ld + 8 * g - a.s0.C;
         }
     };
+    // UNCONDITIONAL: a pixel past the end reads pixel 0 (tile_ptrs clamps) into a B column whose results are never stored.
+    // Behind `if (!mv) return zero` every load sits in its own branch, the compiler can no longer count the loads in
+    // flight, and each wait becomes vmcnt(0): the fragment just re-loaded for the NEXT tile is waited for on the spot --
+    // one exposed memory round trip per k-step instead of none.
     auto load_b = [&](int mt, int ks) -> half8 {
         const int c = ks * 32;                                   // + 8 g is in the pointers
-        if (!mv[mt]) return zero8;
         return *reinterpret_cast<const half8 *>((c < a.s0.C ? p0[mt] : p1[mt]) + c);
     };
 
@@ -417,6 +443,8 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
     for (int ks = 0; ks < KS; ks++)
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) B[mt][ks] = load_b(mt, ks);
+#pragma unroll
+    for (int i = 0; i < KS; i++) s_w[tid + i * 256] = wreg[i];
     __syncthreads();                                             // weights staged
     half_t *out = static_cast<half_t *>(a.out);
     while (t < tiles_total) {
@@ -646,6 +674,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
 #pragma unroll
         for (int i = 0; i < PMAX; i++) {
             if ((IRMV_ABL & 2) && (l_im | l_chunk)) break;
+            // (conditional loads cost nothing here: the next thing this wave does with the ring is write ALL of it to LDS, so
+            // the conservative wait counts they cause -- see conv_mfma_kernel -- wait for nothing that is not needed; made
+            // unconditional, the unused piece slots of the small tiles were extra loads: measured 10 - 15 % slower at MT = 1)
             p[i] = zero8;
             if (val_p[i]) p[i] = *reinterpret_cast<const half8 *>(src_p[i] + off);
         }
