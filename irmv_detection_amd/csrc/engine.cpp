@@ -134,7 +134,7 @@ struct Tensor {
 
 struct SegRef { int t = -1, coff = 0, C = 0, shift = 0; };
 
-enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2, OP_C2F32, OP_DW, OP_SHUF };
+enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2, OP_C2F32, OP_DW, OP_SHUF, OP_SCAN };
 
 struct Op {
     OpKind kind;
@@ -184,6 +184,8 @@ struct irmv_engine {
     irmv_engine_cfg cfg{};
     int nc = 0, nk = 0, A = 0, no = 0;
     int backbone = 0;   // 0: C2f stages (YOLOv8n), 1: ShuffleNetV2 stages (blob header)
+    bool split_scan = true;   // scan + box decode as a multi-workgroup kernel in front of nms_pnp (IRMV_SPLIT_SCAN=0: inside it)
+    int *cand_counts = nullptr;
     bool xcd_order = false;   // conv kernels walk their workgroup lists XCD-contiguously (IRMV_XCD)
     int lvl_hw[3] = {0, 0, 0}, lvl_base[3] = {0, 0, 0};
     size_t frame_bytes = 0;
@@ -916,6 +918,14 @@ static int build_engine(irmv_engine *e)
     // ---- post-processing buffers ----
     TRY(dev_alloc(e, (void **)&e->boxes, (size_t)S * e->A * 16));
     TRY(dev_alloc(e, (void **)&e->keys, (size_t)S * e->A * e->nc * 8));
+    // per-slot candidate counters of the split scan (k_post.hip scan_decode_kernel): zeroed HERE, once, with a synchronous
+    // memset -- afterwards each nms_pnp launch reads its frames' counters and resets them itself (no memset node in a
+    // captured step, nothing left non-zero between steps)
+    { const char *sp = getenv("IRMV_SPLIT_SCAN"); e->split_scan = !(sp && sp[0] == '0'); }
+    if (e->split_scan) {
+        TRY(dev_alloc(e, (void **)&e->cand_counts, (size_t)S * sizeof(int)));
+        HIP_TRY(hipMemset(e->cand_counts, 0, (size_t)S * sizeof(int)));
+    }
     TRY(dev_alloc(e, (void **)&e->dets_dev, (size_t)S * c.max_det * sizeof(DevDet)));
     TRY(dev_alloc(e, (void **)&e->fout_dev, (size_t)S * sizeof(DevFrameOut)));
     HIP_TRY(hipMemset(e->dets_dev, 0, (size_t)S * c.max_det * sizeof(DevDet)));
@@ -933,7 +943,13 @@ static int build_engine(irmv_engine *e)
     log_range(e, "pinned fout_host", e->fout_host, (size_t)S * sizeof(DevFrameOut));
     memset(e->dets_host, 0, (size_t)S * c.max_det * sizeof(DevDet));
     memset(e->fout_host, 0, (size_t)S * sizeof(DevFrameOut));
-    // decode + sort + NMS + keypoints + PnP: one kernel, one workgroup per frame (k_post.hip)
+    // class-logit scan + box decode of the candidate anchors: kScanBlocks workgroups per frame (k_post.hip)
+    if (e->split_scan) {
+        Op op; op.kind = OP_SCAN; op.layer = "scan_decode"; snprintf(op.kname, sizeof op.kname, "scan_decode");
+        snprintf(op.kname_one, sizeof op.kname_one, "scan_decode");
+        op.bytes = (double)e->A * 64.0; e->ops.push_back(op);
+    }
+    // [decode +] sort + NMS + keypoints + PnP: one kernel, one workgroup per frame (k_post.hip)
     { Op op; op.kind = OP_NMS; op.layer = "decode_nms_kpt_pnp"; snprintf(op.kname, sizeof op.kname, "nms_pnp");
       op.bytes = (double)e->A * 64.0; e->ops.push_back(op); }
     if (c.point_source == IRMV_POINTS_KEYPOINT_HEAD && e->nk < 8) return fail(IRMV_ERR_MODEL, "point_source = keypoint head, but the model has none");
@@ -1481,6 +1497,7 @@ static PostArgs post_args(const irmv_engine *e, int first)
     p.dets = (e->zero_copy_results ? e->dets_host_dev : e->dets_dev) + (size_t)first * e->cfg.max_det;
     p.fout = (e->zero_copy_results ? e->fout_host_dev : e->fout_dev) + first;
     if (p.dbg) p.dbg += (size_t)first * 8;
+    p.counts = e->split_scan ? e->cand_counts + first : nullptr;
     return p;
 }
 
@@ -1497,7 +1514,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     bool lane_used[3] = {false, false, false};
     int lane_level[3] = {-1, -1, -1};
     for (const Op &op : e->ops) {
-        if (post_only && op.kind != OP_NMS && op.kind != OP_LIGHT) continue;
+        if (post_only && op.kind != OP_NMS && op.kind != OP_LIGHT && op.kind != OP_SCAN) continue;
         // a step skips the layers a fused kernel covers; a read-back runs only those (and the unfused form of a conv that
         // normally carries a 1x1 in its epilogue)
         if (materialize ? !(op.fused_away || op.fuse_next >= 0) : op.fused_away) continue;
@@ -1511,7 +1528,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             }
             lane_used[ln] = true;
         }
-        if (fork && op.kind == OP_NMS) {        // join the lanes before post-processing
+        if (fork && op.kind == (e->split_scan ? OP_SCAN : OP_NMS)) {        // join the lanes before post-processing
             for (int ln = 0; ln < 3; ln++)
                 if (lane_used[ln]) {
                     HIP_TRY(hipEventRecord(e->ev_join[ln], e->side[ln]));
@@ -1525,7 +1542,10 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             HIP_TRY(hipEventCreate(&r.b));
             HIP_TRY(hipEventRecord(r.a, s));
         }
-        const int reps = (ev && op.kind != OP_LIGHT) ? (int)(flags & 0xffu) : 1;   // every kernel but the light extraction is idempotent
+        // every kernel is idempotent and can be repeated inside its event bracket -- except the light extraction and, with the
+        // split scan, the scan / NMS pair (the scan appends to the frame's candidate list, the NMS kernel consumes and resets it)
+        const bool once = op.kind == OP_LIGHT || (e->split_scan && (op.kind == OP_SCAN || op.kind == OP_NMS));
+        const int reps = (ev && !once) ? (int)(flags & 0xffu) : 1;
         for (int rep = 0; rep < (reps > 0 ? reps : 1); rep++)
         switch (op.kind) {
         case OP_PRE: {
@@ -1630,6 +1650,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             launch_sppf_pool(static_cast<half_t *>(t.slot(first)), count, t.H, t.W, t.C / 4, s);
             break;
         }
+        case OP_SCAN: launch_scan_decode(pa, count, s); break;
         case OP_NMS: launch_nms_pnp(pa, count, s); break;
         case OP_LIGHT: launch_light_extract(light_args(e, first), e->cfg.max_det, count, s); break;
         }
@@ -2091,7 +2112,7 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
         (void)hipEventDestroy(ev[i].a);
         (void)hipEventDestroy(ev[i].b);
         const Op &op = e->ops[ev[i].op];
-        if (op.kind != OP_LIGHT) ms /= (float)kProfileRepeat;
+        if (!(op.kind == OP_LIGHT || (e->split_scan && (op.kind == OP_SCAN || op.kind == OP_NMS)))) ms /= (float)kProfileRepeat;
         if (k < cap && stats) {
             irmv_kernel_stat &st = stats[k];
             memset(&st, 0, sizeof st);

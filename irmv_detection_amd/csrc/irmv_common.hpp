@@ -205,8 +205,13 @@ struct PostArgs {
     int armor_size;
     const PnpConst *pnp;      // device copy (keeps the kernel-argument struct out of scratch)
     long long *dbg;           // optional [B][8] phase stamps of nms_pnp_kernel (diagnostic builds of the engine only)
+    int *counts;              // [B] candidates appended by scan_decode_kernel; nullptr: nms_pnp_kernel scans the head itself.
+                              // Zero at engine creation; nms_pnp_kernel reads its frame's count and resets it (no memset node, nothing
+                              // for another step to find non-zero); every reader clamps it to key_cap
 };
 void launch_nms_pnp(const PostArgs &a, int batch, hipStream_t s);
+constexpr int kScanBlocks = 16;   // workgroups per frame of scan_decode_kernel
+void launch_scan_decode(const PostArgs &a, int batch, hipStream_t s);
 // ---- classical light extraction (k_light.hip) -------------
 constexpr int kLightLdsPoints = 256;         // contours up to this many points are sorted / hulled in LDS
 constexpr int kLightLdsImage = 40 * 1024;   // padded label images up to this many bytes live in LDS

@@ -17,6 +17,8 @@
 #include "irmv_common.hpp"
 #include "pnp_device.hpp"
 
+#include <mutex>
+
 namespace irmv {
 
 // exp(x) as a fixed sequence of fp32 operations (same sequence in oracle/orc_post.c)
@@ -154,6 +156,115 @@ __device__ __forceinline__ void decode_boxes(const PostArgs &a, int b, const uns
     }
 }
 
+// ---------------------------------------------------------------------------
+// Scan + box decode as a kernel of its own, kScanBlocks workgroups per frame.  One workgroup reading a frame's class
+// logits (8400 x 64 B, strided through 384-byte records) is bound by what ONE CU can pull from memory (~30 GB/s): 18 of
+// the 53 us of a single-frame nms_pnp launch, 25 - 30 of 98 us with 64 frames on 64 CUs.  Spread over 16 CUs per frame
+// the same bytes take ~2 us.  Keys go to the frame's global list in whatever order the workgroups append them (the
+// sort of nms_pnp_kernel makes the order irrelevant: keys are unique); the box of every anchor with a candidate is
+// decoded here, four lanes per anchor, exactly as decode_boxes does.
+// ---------------------------------------------------------------------------
+constexpr int kScanU = 2;   // loads in flight per lane: one memory round trip per U * 64 anchors
+static int scan_quads_per_block(int A) { return ((A * 4 + kScanBlocks - 1) / kScanBlocks + 256 * kScanU - 1) / (256 * kScanU) * (256 * kScanU); }
+
+// The workgroup's keys are collected in LDS (sized for every (anchor, class) pair of its range: it cannot overflow) and
+// leave with ONE global atomic per workgroup: one atomic per candidate on the frame's counter serialises in L2 (measured:
+// ~40 ns each, 15 us for 380 candidates -- as long as the scan this kernel was split off to shorten).
+__global__ __launch_bounds__(256) void scan_decode_kernel(PostArgs a, int per)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+    __shared__ int s_n, s_base;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, q = tid & 3, base = lane & ~3;
+    const int quads = a.A * 4;
+    constexpr int U = kScanU;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int w0 = a.net >> 3, A0 = w0 * w0, A1 = A0 + (w0 >> 1) * (w0 >> 1);   // level boundaries
+    unsigned long long *gk = a.keys + (size_t)b * a.key_cap;
+    const int t_end = min((int)(blockIdx.x + 1) * per, quads);
+    for (int t0 = blockIdx.x * per; t0 < t_end; t0 += 256 * U) {
+        f32x4 cl[U];
+        const float *rec[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t0 + u * 256 + tid;
+            const int an = t < quads ? (t >> 2) : 0;
+            const int lbase = an < A0 ? 0 : (an < A1 ? A0 : A1), lhw = an < A0 ? A0 : (an < A1 ? A1 - A0 : a.A - A1);
+            rec[u] = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, an - lbase);
+            cl[u] = reinterpret_cast<const f32x4 *>(rec[u] + kClsOff)[q];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t0 + u * 256 + tid;
+            const bool live = t < quads;
+            const int an = live ? (t >> 2) : 0;
+            bool hit = false;
+#pragma unroll
+            for (int i = 0; i < 4; i++) hit = hit || (live && 4 * q + i < a.nc && cl[u][i] > a.logit_thr);
+            const unsigned long long hits = __ballot(hit);
+            if (hits == 0ull) continue;                            // the common case: nothing in these 16 anchors
+            if (hit) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int c = 4 * q + i;
+                    if (c < a.nc && cl[u][i] > a.logit_thr)
+                        s_keys[atomicAdd(&s_n, 1)] = ((unsigned long long)orderable(cl[u][i]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(an * a.nc + c));
+                }
+            }
+            if (((hits >> base) & 0xfull) != 0ull) {               // this quad's anchor has a candidate: its box, side q on lane q
+                float l[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const f32x4 v = reinterpret_cast<const f32x4 *>(rec[u] + 16 * q)[i];
+                    l[4 * i] = v[0]; l[4 * i + 1] = v[1]; l[4 * i + 2] = v[2]; l[4 * i + 3] = v[3];
+                }
+                const float d = dfl_side(l);
+                // (shuffles inside a divergent region: the four lanes of a quad are active together by construction)
+                const float dl = __shfl(d, base), dt = __shfl(d, base + 1), dr = __shfl(d, base + 2), db = __shfl(d, base + 3);
+                if (q == 0) {
+                    int ix, iy, s, lbase, lhw, rin;
+                    anchor_geom(an, a.net, ix, iy, s, lbase, lhw, rin);
+                    const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)s;
+                    f32x4 box;
+                    box[0] = (ax - dl) * sf;
+                    box[1] = (ay - dt) * sf;
+                    box[2] = (ax + dr) * sf;
+                    box[3] = (ay + db) * sf;
+                    reinterpret_cast<f32x4 *>(a.boxes)[(size_t)b * a.A + an] = box;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    if (tid == 0) s_base = atomicAdd(&a.counts[b], n);
+    __syncthreads();
+    const int gb = s_base;
+    for (int i = tid; i < n; i += 256) {
+        const int idx = gb + i;
+        if (idx >= 0 && idx < a.key_cap) gk[idx] = s_keys[i];     // (a counter that holds garbage cannot push a write outside the list)
+    }
+}
+
+void launch_scan_decode(const PostArgs &a, int batch, hipStream_t s)
+{
+    const int per = scan_quads_per_block(a.A);
+    const size_t lds = (size_t)(per / 4) * a.nc * sizeof(unsigned long long);
+    static std::mutex mu;
+    static size_t raised[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (raised[dev & 63] < lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised[dev & 63] = lds;
+        }
+    }
+    hipLaunchKernelGGL(scan_decode_kernel, dim3(kScanBlocks, batch), dim3(256), lds, s, a, per);
+}
+
 // "IoU(a, b) > thr" as inter > thr * union (same expression as the oracle's iou_gt)
 __device__ __forceinline__ bool iou_gt(const f32x4 a, const f32x4 b, float thr)
 {
@@ -254,6 +365,15 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     if (tid < 16) cls_cnt[tid] = 0;
     if (tid == 0) { s_ncand = 0; s_nanch = 0; }
     __syncthreads();
+    if (a.counts) {
+        // ---- 0'. scan_decode_kernel has filled the frame's key list and decoded the candidate anchors' boxes ----
+        int n = a.counts[b];
+        n = n < 0 ? 0 : (n > a.key_cap ? a.key_cap : n);           // whatever the counter holds, reads stay inside the list
+        if (n <= kCandCap)
+            for (int i = tid; i < n; i += blockDim.x) skeys[i] = gk[i];
+        __syncthreads();                                           // every lane has read the count
+        if (tid == 0) { s_ncand = n; a.counts[b] = 0; }            // the next step of this slot starts from zero
+    } else {
     // ---- 0. decode.  Scan: class logits of every anchor -> candidate keys + the list of anchors that have one.  Level
     // by level (records of a level are contiguous), four lanes per anchor; the loads of U rounds are issued together.
     {
@@ -284,6 +404,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     }
     __syncthreads();
     decode_boxes(a, b, alist, alist ? s_nanch : a.A);   // boxes of the candidate anchors, in parallel over the whole workgroup
+    }
     __syncthreads();   // keys in LDS / global and boxes in global are visible to the whole workgroup from here
     const int n_total = s_ncand;
     int n_stored = n_total;
