@@ -184,6 +184,8 @@ struct irmv_engine {
     irmv_engine_cfg cfg{};
     int nc = 0, nk = 0, A = 0, no = 0;
     int backbone = 0;   // 0: C2f stages (YOLOv8n), 1: ShuffleNetV2 stages (blob header)
+    bool emit_scan = false;   // candidates are emitted by the class-branch conv epilogues (needs split_scan's counters and all three levels fused)
+    int emit_level_abase[3] = {0, 0, 0};
     bool split_scan = true;   // scan + box decode as a multi-workgroup kernel in front of nms_pnp (IRMV_SPLIT_SCAN=0: inside it)
     int *cand_counts = nullptr;
     bool xcd_order = false;   // conv kernels walk their workgroup lists XCD-contiguously (IRMV_XCD)
@@ -1397,6 +1399,18 @@ static int autotune_convs(irmv_engine *e)
 // op drops out of the step and the tensor between the two is no longer written.
 static void finalize_head_fusion(irmv_engine *e)
 {
+    struct Tail {
+        irmv_engine *e;
+        ~Tail()
+        {
+            // candidate emission from the conv epilogues: only if the class branch of EVERY level ends in a fused 1x1
+            int fused = 0;
+            for (const Op &op : e->ops)
+                if (op.kind == OP_CONV && op.fuse_next >= 0 && op.layer.rfind("model.22.cv3.", 0) == 0) fused++;
+            const char *ev = getenv("IRMV_EMIT_SCAN");
+            e->emit_scan = e->split_scan && fused == 3 && !(ev && ev[0] == '0');
+        }
+    } tail{e};
     for (Op &op : e->ops) {
         if (op.fuse_next < 0) continue;
         const bool ok = op.cfg.lds && op.cfg.nt == 4 && op.cfg_one.lds && op.cfg_one.nt == 4;
@@ -1415,6 +1429,7 @@ constexpr uint32_t kProfileRepeat = 4;   // launches per event bracket in irmv_e
 
 static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int count, ConvArgs &a, bool fused)
 {
+    a = ConvArgs{};
     auto seg = [&](const SegRef &s) {
         ConvSeg cs{nullptr, 0, 0, 0};
         if (s.t < 0 || s.C == 0) return cs;
@@ -1515,6 +1530,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     int lane_level[3] = {-1, -1, -1};
     for (const Op &op : e->ops) {
         if (post_only && op.kind != OP_NMS && op.kind != OP_LIGHT && op.kind != OP_SCAN) continue;
+        if (op.kind == OP_SCAN && e->emit_scan && !post_only) continue;   // the class-branch convs have already filled the key lists
         // a step skips the layers a fused kernel covers; a read-back runs only those (and the unfused form of a conv that
         // normally carries a 1x1 in its epilogue)
         if (materialize ? !(op.fused_away || op.fuse_next >= 0) : op.fused_away) continue;
@@ -1641,6 +1657,13 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         case OP_CONV: {
             ConvArgs a;
             fill_conv_args(e, op, first, count, a, !materialize);
+            if (e->emit_scan && !materialize && !post_only && op.fuse_next >= 0 && op.level >= 0 && op.layer.rfind("model.22.cv3.", 0) == 0 &&
+                rep == (reps > 0 ? reps : 1) - 1) {   // (a profiled launch is repeated: only its last repetition appends)
+                a.scan_keys = pa.keys; a.scan_counts = pa.counts; a.scan_thr = pa.logit_thr; a.scan_nc = pa.nc;
+                a.scan_key_cap = pa.key_cap;
+                const int w0 = net / 8;
+                a.scan_abase = op.level == 0 ? 0 : (op.level == 1 ? w0 * w0 : w0 * w0 + (w0 / 2) * (w0 / 2));
+            }
             const ConvCfg &cc = (count == 1 && stream_share(e, e->cfg.num_slots) > 1) ? op.cfg_one : op.cfg;
             if (!run_conv(op, cc, a, count, s)) return fail(IRMV_ERR_ARG, std::string("no conv kernel for ") + op.kname + " (" + op.layer + ")");
             break;
@@ -1651,7 +1674,12 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             break;
         }
         case OP_SCAN: launch_scan_decode(pa, count, s); break;
-        case OP_NMS: launch_nms_pnp(pa, count, s); break;
+        case OP_NMS: {
+            PostArgs pn = pa;
+            pn.keys_only = (e->emit_scan && !post_only) ? 1 : 0;
+            launch_nms_pnp(pn, count, s);
+            break;
+        }
         case OP_LIGHT: launch_light_extract(light_args(e, first), e->cfg.max_det, count, s); break;
         }
         HIP_TRY(hipGetLastError());

@@ -146,6 +146,12 @@ struct ConvArgs {
     float *out2;
     int out2_ld, n2;
     int xcd;            // 1: XCD-aware workgroup order (k_conv.hip xcd_order)
+    // Detect class branch only (the fused 1x1 IS the class-logit conv): candidates are thresholded where the logits are
+    // computed and appended to the frame's key list -- the separate scan over the head tensor then never runs.
+    unsigned long long *scan_keys;   // [B][scan_key_cap], nullptr = off
+    int *scan_counts;                // [B]
+    float scan_thr;
+    int scan_nc, scan_abase, scan_key_cap;   // classes; first anchor index of this level; list capacity (= A * nc)
 };
 
 struct ConvCfg {
@@ -205,6 +211,8 @@ struct PostArgs {
     int armor_size;
     const PnpConst *pnp;      // device copy (keeps the kernel-argument struct out of scratch)
     long long *dbg;           // optional [B][8] phase stamps of nms_pnp_kernel (diagnostic builds of the engine only)
+    int keys_only;            // 1: the key list comes from the class-branch conv epilogues (ConvArgs::scan_keys): nms_pnp_kernel decodes
+                              // the candidates' boxes itself
     int *counts;              // [B] candidates appended by scan_decode_kernel; nullptr: nms_pnp_kernel scans the head itself.
                               // Zero at engine creation; nms_pnp_kernel reads its frame's count and resets it (no memset node, nothing
                               // for another step to find non-zero); every reader clamps it to key_cap

@@ -786,8 +786,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
                             c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][1], ov[1], c2, 0, 0, 0);
                             const int co = t2 * 16 + g * 4;
                             const f32x4 b2 = *reinterpret_cast<const f32x4 *>(s_bias2 + co);
-                            if (mv[mt])
-                                *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) = (f32x4){c2[0] + b2[0], c2[1] + b2[1], c2[2] + b2[2], c2[3] + b2[3]};
+                            const f32x4 v2 = (f32x4){c2[0] + b2[0], c2[1] + b2[1], c2[2] + b2[2], c2[3] + b2[3]};
+                            if (mv[mt]) *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) = v2;
+                            if (a.scan_keys) {
+                                // class logits: lane (g, r) holds classes co .. co + 3 of its pixel -- the values the head record just
+                                // received.  Candidates (rare) go to the frame's key list here, so no kernel re-reads the head for them
+                                // (key format and threshold test of k_post.hip: orderable(logit) << 32 | ~(anchor * nc + class)).
+                                bool hit = false;
+#pragma unroll
+                                for (int i = 0; i < 4; i++) hit = hit || (mv[mt] && co + i < a.scan_nc && v2[i] > a.scan_thr);
+                                if (hit) {
+                                    const int an = a.scan_abase + mloc[mt];
+#pragma unroll
+                                    for (int i = 0; i < 4; i++) {
+                                        if (co + i < a.scan_nc && v2[i] > a.scan_thr) {
+                                            const int idx = atomicAdd(&a.scan_counts[im], 1);
+                                            const unsigned int u = __float_as_uint(v2[i]);
+                                            const unsigned int ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                                            if (idx >= 0 && idx < a.scan_key_cap)
+                                                a.scan_keys[(size_t)im * a.scan_key_cap + idx] =
+                                                    ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned int)(an * a.scan_nc + co + i));
+                                        }
+                                    }
+                                }
+                            }
                         }
                     }
                 } else {

@@ -373,6 +373,39 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             for (int i = tid; i < n; i += blockDim.x) skeys[i] = gk[i];
         __syncthreads();                                           // every lane has read the count
         if (tid == 0) { s_ncand = n; a.counts[b] = 0; }            // the next step of this slot starts from zero
+        if (a.keys_only) {
+            // keys from the class-branch conv epilogues: the candidates' boxes are decoded here, four lanes per candidate (an
+            // anchor with several classes above threshold is decoded once per class: same value, same address)
+            const int q = tid & 3, base = lane & ~3;
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                const int ci = i0 + (tid >> 2);
+                const bool live = ci < n;                          // quad-uniform
+                const unsigned long long key = live ? (n <= kCandCap ? skeys[ci] : gk[ci]) : 0ull;
+                const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
+                int an = live ? (int)(id / (uint32_t)a.nc) : 0;
+                an = an < a.A ? an : 0;                            // (a key list holding garbage cannot push an access outside the head)
+                int ix, iy, st, lbase, lhw, rin;
+                anchor_geom(an, a.net, ix, iy, st, lbase, lhw, rin);
+                const float *rec = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
+                float l[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const f32x4 v = reinterpret_cast<const f32x4 *>(rec + 16 * q)[i];
+                    l[4 * i] = v[0]; l[4 * i + 1] = v[1]; l[4 * i + 2] = v[2]; l[4 * i + 3] = v[3];
+                }
+                const float d = dfl_side(l);
+                const float dl = __shfl(d, base), dt = __shfl(d, base + 1), dr = __shfl(d, base + 2), db = __shfl(d, base + 3);
+                if (live && q == 0) {
+                    const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)st;
+                    f32x4 box;
+                    box[0] = (ax - dl) * sf;
+                    box[1] = (ay - dt) * sf;
+                    box[2] = (ax + dr) * sf;
+                    box[3] = (ay + db) * sf;
+                    reinterpret_cast<f32x4 *>(a.boxes)[(size_t)b * a.A + an] = box;
+                }
+            }
+        }
     } else {
     // ---- 0. decode.  Scan: class logits of every anchor -> candidate keys + the list of anchors that have one.  Level
     // by level (records of a level are contiguous), four lanes per anchor; the loads of U rounds are issued together.
