@@ -49,14 +49,24 @@ public:
     return v ? std::atoi(v) : 0;
   }
 
-  // The reference's constructor (yolo_engine.hpp:28-30).  Extension arguments: `device` (HIP ordinal, -1 = default_device())
-  // and `warm_up_now` (false: the owner calls warm_up() itself, e.g. after building several engines).
+  // Network input size when none is given: IRMV_NET_SIZE (a multiple of 32), else the reference's hard-coded 640
+  // (src/yolo_engine.cpp:98-99); BASELINE configs[4] runs its model at 416.
+  static int default_net_size()
+  {
+    const char * v = std::getenv("IRMV_NET_SIZE");
+    return v ? std::atoi(v) : 640;
+  }
+
+  // The reference's constructor (yolo_engine.hpp:28-30).  Extension arguments: `device` (HIP ordinal, -1 = default_device()),
+  // `warm_up_now` (false: the owner calls warm_up() itself, e.g. after building several engines) and `net_size`
+  // (-1 = default_net_size()).  The model file decides the architecture (YOLOv8n or its ShuffleNetV2-backbone variant).
   YoloEngine(const std::string & onnx_file_path, cv::Size src_image_size, bool enable_profiling = false, int device = -1,
-             bool warm_up_now = true)
+             bool warm_up_now = true, int net_size = -1)
   : src_image_size_(src_image_size), enable_profiling_(enable_profiling)
   {
     irmv_engine_cfg cfg;
     irmv_engine_cfg_default(&cfg);
+    cfg.net_size = net_size > 0 ? net_size : default_net_size();
     cfg.device = device >= 0 ? device : default_device();
     cfg.src_width = src_image_size.width;
     cfg.src_height = src_image_size.height;

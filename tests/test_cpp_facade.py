@@ -123,3 +123,27 @@ def test_irm_detector_core_vs_oracle(tmp_path, blob, rm_test_image, kind):
     assert m and int(m.group(1)) > 0
     if kind == "kpt":
         assert int(m.group(2)) > 0
+
+
+@pytest.mark.gpu
+def test_reference_test_flow_second_model_int8_416(tmp_path, frame0):
+    """BASELINE configs[4] through the C++ facade: the reference's test program on the ShuffleNetV2-backbone variant with an
+    int8 weight blob at a 416 x 416 network input (IRMV_NET_SIZE): same detections as the Python binding on that model."""
+    from irmv_detection_amd import arch, weights
+    from irmv_detection_amd.engine import YoloEngine
+    exe = os.path.join(BIN, "yolo_test")
+    if not os.path.exists(exe):
+        exe = _compile("yolo_test.cpp", exe, True)
+    blob = weights.quantize_blob_int8(weights.synthetic_blob(0, backbone=arch.BACKBONE_SHUFFLE))
+    (tmp_path / "yolov7.irmw").write_bytes(blob)
+    frame0.tofile(tmp_path / "frame.bin")
+    env = dict(os.environ, IRMV_NET_SIZE="416")
+    out = subprocess.run([exe, str(tmp_path / "yolov7.onnx"), str(tmp_path / "frame.bin"), "3"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    with YoloEngine(None, (1280, 1024), weights_blob=blob, net_size=416) as e:
+        e.get_src_image_buffer()[:] = frame0
+        bb = e.detect()
+    assert len(bb) > 0
+    assert int(re.search(r"bboxes (\d+)", out.stdout).group(1)) == len(bb)
+    first = [float(v) for v in re.search(r"bbox 0 (\S+) (\S+) (\S+) (\S+) (\S+)", out.stdout).groups()]
+    assert np.allclose(first[:4], bb[0].xyxy, atol=1e-4) and abs(first[4] - bb[0].score) < 1e-5
