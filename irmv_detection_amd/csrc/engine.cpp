@@ -159,6 +159,7 @@ struct Op {
     bool shortcut = false;
     int fuse_next = -1;        // LDS 3x3 conv: index of the 1x1 op computed in its epilogue (Detect-head finals), -1 = none
     bool fused_away = false;   // preprocess / model.0 / model.1 when the fused front kernel runs them (kept for read-backs)
+    int group = -1;            // single-frame steps: index into irmv_engine::head_groups of the one launch this conv rides in
 };
 
 struct GraphKey {
@@ -184,6 +185,10 @@ struct irmv_engine {
     irmv_engine_cfg cfg{};
     int nc = 0, nk = 0, A = 0, no = 0;
     int backbone = 0;   // 0: C2f stages (YOLOv8n), 1: ShuffleNetV2 stages (blob header)
+    // Single-frame engines: the independent Detect-branch convs of the three levels as one launch per stage (k_conv.hip
+    // conv3x3_lds_multi / conv_mfma_multi).  family 0: LDS 3x3 with tile (mt 1, nt); 1: direct kernel with cfg.
+    struct HeadGroup { std::vector<int> members; int family = 0, nt = 1; ConvCfg cfg{}; char name[48] = {0}; };
+    std::vector<HeadGroup> head_groups;
     bool emit_scan = false;   // candidates are emitted by the class-branch conv epilogues (needs split_scan's counters and all three levels fused)
     int emit_level_abase[3] = {0, 0, 0};
     bool split_scan = true;   // scan + box decode as a multi-workgroup kernel in front of nms_pnp (IRMV_SPLIT_SCAN=0: inside it)
@@ -651,6 +656,7 @@ static bool front_fits(const std::vector<AxisTap> &tx, const std::vector<AxisTap
 
 static int autotune_convs(irmv_engine *e);
 static void finalize_head_fusion(irmv_engine *e);
+static int build_head_groups(irmv_engine *e);
 
 static int build_engine(irmv_engine *e)
 {
@@ -1140,6 +1146,8 @@ extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
     rc = autotune_convs(e.get());
     if (rc) return rc;
     finalize_head_fusion(e.get());
+    rc = build_head_groups(e.get());
+    if (rc) return rc;
     *out = e.release();
     return IRMV_OK;
 }
@@ -1423,6 +1431,133 @@ static void finalize_head_fusion(irmv_engine *e)
     }
 }
 
+// ---- grouped Detect-branch launches (single-frame engines) ---------------------------
+static void scan_args_for(const irmv_engine *e, const Op &op, const PostArgs &pa, ConvArgs &a)
+{
+    a.scan_keys = pa.keys; a.scan_counts = pa.counts; a.scan_thr = pa.logit_thr; a.scan_nc = pa.nc;
+    a.scan_key_cap = pa.key_cap;
+    const int w0 = e->cfg.net_size / 8;
+    a.scan_abase = op.level == 0 ? 0 : (op.level == 1 ? w0 * w0 : w0 * w0 + (w0 / 2) * (w0 / 2));
+}
+
+static bool is_cls_final_carrier(const Op &op) { return op.fuse_next >= 0 && op.level >= 0 && op.layer.rfind("model.22.cv3.", 0) == 0; }
+
+// one launch for all members of group g on slot `first`; pa == nullptr: no candidate emission (timing, profile repeats)
+static bool launch_head_group(const irmv_engine *e, const irmv_engine::HeadGroup &g, int first, const PostArgs *pa, hipStream_t s)
+{
+    ConvArgs a[kMultiMax];
+    const half_t *wl[kMultiMax];
+    const int n = (int)g.members.size();
+    for (int k = 0; k < n; k++) {
+        const Op &op = e->ops[g.members[k]];
+        fill_conv_args(e, op, first, 1, a[k], true);
+        if (pa && e->emit_scan && is_cls_final_carrier(op)) scan_args_for(e, op, *pa, a[k]);
+        wl[k] = op.w_lds[g.nt == 4 ? 2 : (g.nt == 2 ? 1 : 0)];
+        if (g.family == 0 && !wl[k]) return false;
+    }
+    return g.family == 0 ? launch_conv_lds_multi(g.nt, a, wl, n, 1, s) : launch_conv_direct_multi(g.cfg, a, n, s);
+}
+
+static int build_head_groups(irmv_engine *e)
+{
+    const char *gh = getenv("IRMV_GROUP_HEAD");
+    if (!e->merge_head0 || e->fork_head || (gh && gh[0] == '0')) return IRMV_OK;
+    auto find_op = [&](const std::string &layer) {
+        for (size_t i = 0; i < e->ops.size(); i++)
+            if (e->ops[i].kind == OP_CONV && !e->ops[i].fused_away && e->ops[i].layer == layer) return (int)i;
+        return -1;
+    };
+    auto time_of = [&](auto &&launch) {   // ms per launch, or < 0 if it cannot run
+        for (int i = 0; i < 2; i++) if (!launch()) return -1.f;
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return -1.f;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.f;
+        (void)hipEventRecord(a, e->stream);
+        for (int i = 0; i < 8; i++) launch();
+        (void)hipEventRecord(b, e->stream);
+        (void)hipEventSynchronize(b);
+        float ms = -1.f;
+        (void)hipEventElapsedTime(&ms, a, b);
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        return ms / 8.f;
+    };
+    auto members_time = [&](const std::vector<int> &mem) {
+        return time_of([&] {
+            for (int i : mem) {
+                const Op &op = e->ops[i];
+                ConvArgs a;
+                fill_conv_args(e, op, 0, 1, a, true);
+                if (!run_conv(op, op.cfg_one, a, 1, e->stream)) return false;
+            }
+            return true;
+        });
+    };
+    auto try_group = [&](std::vector<int> mem, int family, std::vector<int> nts, const char *label) {
+        for (int i : mem) if (i < 0) return;
+        if (mem.size() < 2 || mem.size() > (size_t)kMultiMax) return;
+        irmv_engine::HeadGroup best;
+        float best_ms = -1.f;
+        for (int nt : nts) {
+            irmv_engine::HeadGroup g;
+            g.members = mem; g.family = family; g.nt = nt;
+            if (family == 1) {
+                g.cfg = e->ops[mem[0]].cfg_one;
+                bool same = !g.cfg.lds && !g.cfg.ct && !g.cfg.pw;   // (the members' own tile shapes and prefetch depths are bitwise neutral: the group runs mt = nt = 1)
+                for (int i : mem) {
+                    const ConvCfg &c = e->ops[i].cfg_one;
+                    same = same && c.ks == g.cfg.ks && c.stride == g.cfg.stride && c.cin16 == g.cfg.cin16 && c.act == g.cfg.act && c.out_f32 == g.cfg.out_f32 && !c.lds && !c.ct && !c.pw;
+                }
+                if (!same) continue;
+                g.cfg.mt = g.cfg.nt = 1; g.cfg.deep = false;
+            } else {
+                bool fam = true;   // every member must belong to the LDS family's K order (its single-frame choice is an LDS tile or the CT stand-in)
+                for (int i : mem) fam = fam && (e->ops[i].cfg_one.lds || e->ops[i].cfg_one.ct);
+                if (!fam) continue;
+            }
+            if (getenv("IRMV_GROUP_VERBOSE")) { fprintf(stderr, "[irmv group] timing %s nt %d ...\n", label, nt); fflush(stderr); }
+            const float ms = time_of([&] { return launch_head_group(e, g, 0, nullptr, e->stream); });
+            if (getenv("IRMV_GROUP_VERBOSE")) { fprintf(stderr, "[irmv group] ... %.2f us\n", ms * 1e3f); fflush(stderr); }
+            if (ms > 0.f && (best_ms < 0.f || ms < best_ms)) { best_ms = ms; best = g; }
+        }
+        if (best_ms < 0.f) return;
+        const float sep = members_time(mem);
+        if (getenv("IRMV_AUTOTUNE_VERBOSE") || getenv("IRMV_GROUP_VERBOSE")) fprintf(stderr, "[irmv group] %s: %zu convs, one launch %.2f us, separate %.2f us\n", label, mem.size(), best_ms * 1e3f, sep * 1e3f);
+        if (sep > 0.f && best_ms >= sep && !getenv("IRMV_GROUP_FORCE")) return;
+        if (family == 0) snprintf(best.name, sizeof best.name, "%s_lds_mt1_nt%d_x%zu", label, best.nt, mem.size());
+        else snprintf(best.name, sizeof best.name, "%s_direct_x%zu", label, mem.size());
+        const int gi = (int)e->head_groups.size();
+        e->head_groups.push_back(best);
+        for (int i : mem) e->ops[i].group = gi;
+    };
+    const bool kpt = e->nk > 0;
+    std::vector<int> g1, g2, g3, g4;
+    bool g2_fused = true;
+    for (int i = 0; i < 3; i++) {
+        const std::string si = std::to_string(i);
+        g1.push_back(find_op("model.22.s0." + si));
+        const int c2 = find_op("model.22.cv2." + si + ".1"), c3 = find_op("model.22.cv3." + si + ".1");
+        g2.push_back(c2); g2.push_back(c3);
+        g2_fused = g2_fused && c2 >= 0 && c3 >= 0 && e->ops[c2].fuse_next >= 0 && e->ops[c3].fuse_next >= 0;
+        if (kpt) { g3.push_back(find_op("model.22.cv4." + si + ".1")); g4.push_back(find_op("model.22.cv4." + si + ".2")); }
+    }
+    {
+        const char *fnt = getenv("IRMV_GROUP_S0_NT");   // diagnostic: pin the first-stage group's channel tiling
+        if (fnt) try_group(g1, 0, {atoi(fnt)}, "head_s0");
+        else try_group(g1, 0, {1, 2}, "head_s0");
+    }
+    if (g2_fused) try_group(g2, 0, {4}, "head_s1+1x1");
+    // A group is launched where its FIRST member stands in the op list, so every member's input must exist by then.  The
+    // first-stage convs precede all of these; the keypoint finals (cv4.i.2) read cv4.i.1, and cv4.1.1 / cv4.2.1 stand BEHIND
+    // cv4.0.2 in the list: the finals may only be grouped when the convs before them are (one launch, at cv4.0.1's place).
+    if (kpt) {
+        const size_t before = e->head_groups.size();
+        try_group(g3, 1, {1}, "head_kpt1");
+        if (e->head_groups.size() > before) try_group(g4, 1, {1}, "head_kpt2");
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return IRMV_OK;
+}
+
 // ---- step execution ------------------------------------------------------------
 struct EvRec { hipEvent_t a = nullptr, b = nullptr; int op = -1; };
 constexpr uint32_t kProfileRepeat = 4;   // launches per event bracket in irmv_engine_profile
@@ -1531,6 +1666,8 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     for (const Op &op : e->ops) {
         if (post_only && op.kind != OP_NMS && op.kind != OP_LIGHT && op.kind != OP_SCAN) continue;
         if (op.kind == OP_SCAN && e->emit_scan && !post_only) continue;   // the class-branch convs have already filled the key lists
+        const bool grouped = op.kind == OP_CONV && op.group >= 0 && count == 1 && !materialize && !post_only;
+        if (grouped && e->head_groups[op.group].members[0] != (int)(&op - e->ops.data())) continue;   // rides in its group's launch
         // a step skips the layers a fused kernel covers; a read-back runs only those (and the unfused form of a conv that
         // normally carries a 1x1 in its epilogue)
         if (materialize ? !(op.fused_away || op.fuse_next >= 0) : op.fused_away) continue;
@@ -1655,15 +1792,15 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             break;
         }
         case OP_CONV: {
+            if (grouped) {   // (a profiled launch is repeated: only its last repetition appends candidates)
+                if (!launch_head_group(e, e->head_groups[op.group], first, rep == (reps > 0 ? reps : 1) - 1 ? &pa : nullptr, s))
+                    return fail(IRMV_ERR_ARG, std::string("grouped launch refused: ") + e->head_groups[op.group].name);
+                break;
+            }
             ConvArgs a;
             fill_conv_args(e, op, first, count, a, !materialize);
-            if (e->emit_scan && !materialize && !post_only && op.fuse_next >= 0 && op.level >= 0 && op.layer.rfind("model.22.cv3.", 0) == 0 &&
-                rep == (reps > 0 ? reps : 1) - 1) {   // (a profiled launch is repeated: only its last repetition appends)
-                a.scan_keys = pa.keys; a.scan_counts = pa.counts; a.scan_thr = pa.logit_thr; a.scan_nc = pa.nc;
-                a.scan_key_cap = pa.key_cap;
-                const int w0 = net / 8;
-                a.scan_abase = op.level == 0 ? 0 : (op.level == 1 ? w0 * w0 : w0 * w0 + (w0 / 2) * (w0 / 2));
-            }
+            if (e->emit_scan && !materialize && !post_only && is_cls_final_carrier(op) && rep == (reps > 0 ? reps : 1) - 1)
+                scan_args_for(e, op, pa, a);   // (a profiled launch is repeated: only its last repetition appends)
             const ConvCfg &cc = (count == 1 && stream_share(e, e->cfg.num_slots) > 1) ? op.cfg_one : op.cfg;
             if (!run_conv(op, cc, a, count, s)) return fail(IRMV_ERR_ARG, std::string("no conv kernel for ") + op.kname + " (" + op.layer + ")");
             break;
@@ -2144,10 +2281,21 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
         if (k < cap && stats) {
             irmv_kernel_stat &st = stats[k];
             memset(&st, 0, sizeof st);
+            if (op.kind == OP_CONV && op.group >= 0 && count == 1) {   // one launch for the whole group
+                const irmv_engine::HeadGroup &g = e->head_groups[op.group];
+                snprintf(st.name, sizeof st.name, "%s", g.name);
+                snprintf(st.layer, sizeof st.layer, "%s ... (%zu convs)", op.layer.c_str(), g.members.size());
+                for (int mi : g.members) {
+                    const Op &mo = e->ops[mi];
+                    st.flops += mo.flops + (mo.fuse_next >= 0 ? e->ops[mo.fuse_next].flops : 0.0);
+                    st.bytes += mo.bytes;
+                }
+            } else {
             snprintf(st.name, sizeof st.name, "%s", (count == 1 && stream_share(e, e->cfg.num_slots) > 1 && op.kind == OP_CONV) ? op.kname_one : op.kname);
             snprintf(st.layer, sizeof st.layer, "%s", op.layer.c_str());
             st.flops = (op.flops + (op.fuse_next >= 0 ? e->ops[op.fuse_next].flops : 0.0)) * count;
             st.bytes = op.bytes * count;
+            }
             st.ms = ms;
         }
         k++;

@@ -154,6 +154,25 @@ struct ConvArgs {
     int scan_nc, scan_abase, scan_key_cap;   // classes; first anchor index of this level; list capacity (= A * nc)
 };
 
+// several independent layers in one launch (k_conv.hip conv3x3_lds_multi / conv_mfma_multi)
+constexpr int kMultiMax = 6;
+struct LdsMember {
+    ConvArgs a;
+    const half_t *wl;
+    int tiles_x, tiles_y, twc_log2, patch_bytes, batch, tile2d;
+    int gx, gy;                 // this member's grid
+};
+struct LdsMultiArgs {
+    int n;
+    int start[kMultiMax + 1];   // first workgroup of member k
+    LdsMember m[kMultiMax];
+};
+struct DirectMultiArgs {
+    int n;
+    int start[kMultiMax + 1], gx[kMultiMax], gy[kMultiMax];
+    ConvArgs a[kMultiMax];
+};
+
 struct ConvCfg {
     int ks, stride, mt, nt; bool cin16; int act; bool out_f32; bool lds; int ipw;   // ipw: images per workgroup (LDS family)
     bool deep;   // direct kernel, latency variant: prefetch ring of 6..12 k-steps (single-frame steps)
@@ -165,6 +184,11 @@ struct ConvCfg {
 bool launch_conv(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 const char *conv_cfg_name(const ConvCfg &cfg, char *buf, int n);
 bool conv_pw_eligible(const ConvCfg &cfg, const ConvArgs &a);
+// n independent layers (n <= kMultiMax) as ONE launch with a common tile: LDS family, stride 1, mt = 1, nt in {1, 2, 4}
+// (fused 1x1s allowed at nt = 4, per member); direct family: the two shapes of the keypoint branch (3x3 Cin = 16 SiLU,
+// 1x1 fp32 bias-only; mt = nt = 1).  false: some member has no such tile.
+bool launch_conv_lds_multi(int nt, const ConvArgs *a, const half_t *const *wl, int n, int batch, hipStream_t s);
+bool launch_conv_direct_multi(const ConvCfg &cfg, const ConvArgs *a, int n, hipStream_t s);
 bool launch_conv_pw(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 // LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt
 size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max);

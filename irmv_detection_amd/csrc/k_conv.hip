@@ -43,18 +43,18 @@ __device__ __forceinline__ int xcd_order(int lin, int nwg)
 }
 
 template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32, bool CT = false, bool DEEP = false>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, int wg_x, int wg_y, int grid_x, int grid_y)
 {
     constexpr int PAD = KS / 2;
     constexpr int PF = DEEP ? DeepPrefetchDepth<MT, NT>::value : PrefetchDepth<MT, NT>::value;
     static_assert(!CT || (KS == 3 && !CIN16), "chunk-major order is the 3x3 LDS family's");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
-    int bx = blockIdx.x, by = blockIdx.y;
+    int bx = wg_x, by = wg_y;
     if (a.xcd) {   // list order: pixel block major (= image major), then output-channel block
-        const int L = xcd_order(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
-        bx = L / (int)gridDim.y;
-        by = L - bx * (int)gridDim.y;
+        const int L = xcd_order(wg_x + wg_y * grid_x, grid_x * grid_y);
+        bx = L / grid_y;
+        by = L - bx * grid_y;
     }
     const int tile0 = (bx * 4 + wave) * MT;
     const int nt0 = by * NT;
@@ -250,6 +250,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 }
 
 template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32, bool CT = false, bool DEEP = false>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
+{
+    conv_mfma_body<KS, STRIDE, MT, NT, CIN16, ACT, OUT_F32, CT, DEEP>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// several independent layers of one kernel shape in one launch (see conv3x3_lds_multi)
+template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256) void conv_mfma_multi(DirectMultiArgs m)
+{
+    int id = blockIdx.x, k = 0;
+    while (k + 1 < m.n && id >= m.start[k + 1]) k++;
+    id -= m.start[k];
+    const int gx = m.gx[k], gy = m.gy[k];
+    conv_mfma_body<KS, STRIDE, MT, NT, CIN16, ACT, OUT_F32>(m.a[k], id % gx, id / gx, gx, gy);
+}
+
+template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32, bool CT = false, bool DEEP = false>
 static void launch_inst(const ConvArgs &a, hipStream_t s)
 {
     const int tiles = (a.M + 15) / 16;
@@ -318,6 +335,32 @@ bool launch_conv(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
     IRMV_CASE(1, 1, false, 1, false)   // 1x1 SiLU
     IRMV_CASE(1, 1, false, 0, true)    // 1x1 head finals: bias only, fp32 out
 #undef IRMV_CASE
+    return false;
+}
+
+bool launch_conv_direct_multi(const ConvCfg &c, const ConvArgs *a, int n, hipStream_t s)
+{
+    if (n < 1 || n > kMultiMax || c.mt != 1 || c.nt != 1 || c.deep || c.ct || c.lds || c.pw) return false;
+    DirectMultiArgs m{};
+    m.n = n;
+    int total = 0;
+    for (int k = 0; k < n; k++) {
+        if (a[k].cout_pad % 16 != 0) return false;
+        m.a[k] = a[k];
+        m.start[k] = total;
+        m.gx[k] = ((a[k].M + 15) / 16 + 3) / 4;
+        m.gy[k] = a[k].cout_pad / 16;
+        total += m.gx[k] * m.gy[k];
+    }
+    m.start[n] = total;
+    if (c.ks == 3 && c.stride == 1 && c.cin16 && c.act == 1 && !c.out_f32) {
+        hipLaunchKernelGGL((conv_mfma_multi<3, 1, 1, 1, true, 1, false>), dim3(total), dim3(256), 0, s, m);
+        return true;
+    }
+    if (c.ks == 1 && c.stride == 1 && !c.cin16 && c.act == 0 && c.out_f32) {
+        hipLaunchKernelGGL((conv_mfma_multi<1, 1, 1, 1, false, 0, true>), dim3(total), dim3(256), 0, s, m);
+        return true;
+    }
     return false;
 }
 
@@ -549,8 +592,11 @@ __device__ int g_stagger_sleeps = 0;
 #ifndef IRMV_LDS_WAVES
 #define IRMV_LDS_WAVES 2   // minimum waves per SIMD the register allocation aims at (A/B: scripts/gpu_stage.sh abwaves)
 #endif
+// The kernel's body as a device function of (workgroup index, grid size), so that one launch can serve several layers
+// (conv3x3_lds_multi below); conv3x3_lds_kernel itself is the thin wrapper behind it.
 template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
+__device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch,
+                                                 int wg_x, int wg_y, int grid_x, int grid_y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
@@ -564,10 +610,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
     //            of staging full-width rows.
     // A workgroup keeps its tile position for `ipw` consecutive images: the staging plan below is computed once,
     // and the load -> LDS -> MFMA pipeline runs through all (image, chunk) steps without draining.
-    int bx = blockIdx.x, by = blockIdx.y;
+    int bx = wg_x, by = wg_y;
     if (a.xcd) {   // list order: image group, then output-channel block, then tile
-        const int tiles = tiles_x * tiles_y, nby = gridDim.y;
-        const int L = xcd_order(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * nby);
+        const int tiles = tiles_x * tiles_y, nby = grid_y;
+        const int L = xcd_order(wg_x + wg_y * grid_x, grid_x * nby);
         const int g_ = L / (tiles * nby), rem = L - g_ * (tiles * nby);
         by = rem / tiles;
         bx = g_ * tiles + (rem - by * tiles);
@@ -989,6 +1035,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
     }
 }
 
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
+{
+    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// Several independent 3x3 layers in ONE launch (the Detect branches of the three levels in a single-frame step: fifteen
+// launches of 4 - 8 us, most of it launch and ramp, become four).  Every member runs the body above with its own
+// arguments and geometry on its own range of workgroups; tile shape (MT, NT) is the group's, the block scheme (2-D block
+// or row run) and the fused 1x1 (none / class branch / box branch) are the member's.
+template <int STRIDE, int MT, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_multi(LdsMultiArgs m)
+{
+    int id = blockIdx.x, k = 0;
+    while (k + 1 < m.n && id >= m.start[k + 1]) k++;
+    id -= m.start[k];
+    const LdsMember &l = m.m[k];
+    const int wx = id % l.gx, wy = id / l.gx;
+#define IRMV_BODY(T2D_, N2_) conv3x3_lds_body<STRIDE, MT, NT, T2D_, N2_>(l.a, l.wl, l.tiles_x, l.tiles_y, l.twc_log2, l.patch_bytes, 1, l.batch, wx, wy, l.gx, l.gy)
+    if constexpr (NT == 4) {
+        if (l.a.n2 == 4) { if (l.tile2d) IRMV_BODY(true, 4); else IRMV_BODY(false, 4); return; }
+        if (l.a.n2 == 1) { if (l.tile2d) IRMV_BODY(true, 1); else IRMV_BODY(false, 1); return; }
+    }
+    if (l.tile2d) IRMV_BODY(true, 0); else IRMV_BODY(false, 0);
+#undef IRMV_BODY
+}
+
 // Geometry of the LDS kernel for one layer and tile shape.  The 2-D block scheme is used when the
 // block tiles the image exactly (no masked lanes); otherwise the row-run scheme.  bytes == 0: not eligible.
 struct LdsGeom { bool tile2d; int tiles_x, tiles_y, twc_log2, patch_bytes; size_t bytes; };
@@ -1084,6 +1157,41 @@ bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, con
     IRMV_LDS(2, 1, 1) IRMV_LDS(2, 2, 1) IRMV_LDS(2, 4, 1)
     IRMV_LDS(2, 1, 2) IRMV_LDS(2, 2, 2) IRMV_LDS(2, 4, 2) IRMV_LDS(2, 1, 4) IRMV_LDS(2, 2, 4) IRMV_LDS(2, 4, 4)
 #undef IRMV_LDS
+    return false;
+}
+
+bool launch_conv_lds_multi(int nt, const ConvArgs *a, const half_t *const *wl, int n, int batch, hipStream_t s)
+{
+    if (n < 1 || n > kMultiMax || !(nt == 1 || nt == 2 || nt == 4)) return false;
+    LdsMultiArgs m{};
+    m.n = n;
+    int total = 0;
+    size_t bytes = 0;
+    for (int k = 0; k < n; k++) {
+        const LdsGeom g = lds_geom(a[k], 1, 1, nt);
+        if (!g.bytes) return false;
+        if (a[k].n2 > 0 && (nt != 4 || a[k].cout_pad != 64 || !a[k].pair || a[k].res || !(a[k].n2 == 1 || a[k].n2 == 4))) return false;
+        LdsMember &l = m.m[k];
+        l.a = a[k]; l.wl = wl[k];
+        l.tiles_x = g.tiles_x; l.tiles_y = g.tiles_y; l.twc_log2 = g.twc_log2; l.patch_bytes = g.patch_bytes; l.batch = batch; l.tile2d = g.tile2d ? 1 : 0;
+        l.gx = g.tiles_x * g.tiles_y * batch;       // one image per workgroup
+        l.gy = a[k].cout_pad / (16 * nt);
+        m.start[k] = total;
+        total += l.gx * l.gy;
+        bytes = bytes > g.bytes ? bytes : g.bytes;
+    }
+    m.start[n] = total;
+#define IRMV_LDS_M(NT_)                                                                                                  \
+    if (nt == NT_) {                                                                                                      \
+        static unsigned long long attr_done = 0;                                                                          \
+        once_per_device(attr_done, [] {                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_multi<1, 1, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        });                                                                                                               \
+        hipLaunchKernelGGL((conv3x3_lds_multi<1, 1, NT_>), dim3(total), dim3(256), bytes, s, m);                          \
+        return true;                                                                                                      \
+    }
+    IRMV_LDS_M(1) IRMV_LDS_M(2) IRMV_LDS_M(4)
+#undef IRMV_LDS_M
     return false;
 }
 

@@ -12,6 +12,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The CPU oracle is OpenMP code.  A GPU box shows every host CPU but grants a share of them: a team as large as the visible
+# CPU count, spinning at its barriers, turns a 64 x 64 forward pass into a minute.  Before liboracle.so (libgomp) loads:
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, len(os.sched_getaffinity(0))))))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -441,6 +441,32 @@ def test_merged_head_first_stage_is_bitwise_the_separate_convs(blob, frame0, mon
         assert not any(st["layer"].startswith("model.22.s0.") for st in e.profile(0, 4))
 
 
+def test_grouped_detect_launches_are_bitwise_the_separate_convs(blob, monkeypatch):
+    """Single-frame engines run the independent Detect-branch convs of the three levels as one launch per stage
+    (conv3x3_lds_multi / conv_mfma_multi): same kernels on the same operands, so same bits -- head tensor, the second-stage
+    activations, candidates and detections -- for pose and bbox-only models, at 640 and 416."""
+    from irmv_detection_amd import weights
+    for b, net in ((blob, 640), (weights.synthetic_blob(0, nk=0), 640), (blob, 416)):
+        outs = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("IRMV_GROUP_HEAD", mode)
+            with YoloEngine(None, (1280, 1024), weights_blob=b, net_size=net, point_source=capi.POINTS_AUTO) as e:
+                names = [st["name"] for st in e.profile(0, 1)]
+                assert any(n.startswith("head_s0_lds") for n in names) == (mode == "1")
+                assert any(n.startswith("head_s1+1x1_lds") for n in names) == (mode == "1")
+                if mode == "1":
+                    assert len(names) <= 46          # 40 with all four groups; the keypoint pair forms only when it times faster
+                _load(e, 0, frames.synthetic_frame(3))
+                e.detect()
+                raw = e.read_raw(0)
+                outs.append((e.read_head(0).copy(), e.read_tap("22.cv2.1.1", 0).copy(), e.read_tap("22.cv3.0.1", 0).copy(),
+                             raw["boxes"].copy(), raw["scores"].copy(), raw["anchors"].copy(), np.array([raw["n_candidates"], raw["num_dets"]])))
+        for i, (x, y) in enumerate(zip(*outs)):
+            assert np.array_equal(x, y), (net, i, names)
+        assert net != 640 or outs[0][-1][1] > 0          # (frame 3 has candidates at 640; none at 416 with the 640-calibrated weights)
+    monkeypatch.delenv("IRMV_GROUP_HEAD")
+
+
 def _bench_tune_cache(tmp_path, monkeypatch):
     """Seed the autotuner exactly as bench.py does (its own copy of profiles/*_tune_cache.txt)."""
     import os, shutil
@@ -570,7 +596,7 @@ def test_fused_kernels_are_bitwise_identical(blob, monkeypatch, size, net, mode,
             assert ("front_fused" in names) == (env == "1" and fused)
             assert ("c2f2_fused" in names) == (env == "1")
             assert ("c2f32_ab" in names and "c2f32_a" in names and "c2f32_b" in names) == (env == "1")   # model.15; model.4
-            assert any(n.endswith("+1x1") for n in names) == (env == "1")       # Detect finals inside the 3x3 epilogue
+            assert any("+1x1" in n for n in names) == (env == "1")              # Detect finals inside the 3x3 epilogue (single launches or the grouped one)
             _load(e, 0, img)
             e.detect()
             got.append((e.read_tap("1", 0).copy(), e.read_head(0).copy(), e.read_input(0).copy(), e.read_tap("0", 0).copy(),
@@ -579,5 +605,10 @@ def test_fused_kernels_are_bitwise_identical(blob, monkeypatch, size, net, mode,
                         e.read_tap("model.4.cat", 0).copy(), e.read_tap("model.15.cat", 0).copy(), e.read_tap("model.4.tmp", 0).copy()))
     labels = ("1", "head", "input", "0", "2", "model.2.cat", "22.cv2.0.1", "22.cv3.2.1", "4", "15", "model.4.cat", "model.15.cat", "model.4.tmp")
     differ = [lb for lb, a, b in zip(labels, got[0], got[1]) if not np.array_equal(a, b)]
-    assert not differ, (differ, kernels)
+    where = ""
+    for lb, a, b in zip(labels, got[0], got[1]):
+        if lb == "head" and not np.array_equal(a, b):
+            d = np.abs(a - b)
+            where = f"head rows {np.nonzero(d.max(1) > 0)[0][:12].tolist()} cols {np.nonzero(d.max(0) > 0)[0][:24].tolist()} max {d.max()}"
+    assert not differ, (differ, where, kernels)
     assert np.abs(got[0][0]).max() > 0.1
