@@ -1204,7 +1204,7 @@ bool launch_conv_lds_multi(int nt, const ConvArgs *a, const half_t *const *wl, i
 // pass 2 takes the vertical maxima of those: 13 + 27 LDS reads per (pixel, 8
 // channels) instead of 169 global loads.  Max is exact, so this is bit-identical
 // to the chained pools.
-__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(half_t *buf, int H, int W, int C, int CW)
+__global__ __launch_bounds__(512) void sppf_pool_lds_kernel(half_t *buf, int H, int W, int C, int CW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int HW = H * W, chunks = CW >> 3;
@@ -1343,7 +1343,9 @@ void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s
         once_per_device(attr_done, [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sppf_pool_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-        hipLaunchKernelGGL(sppf_pool_lds_kernel, dim3(batch * (C / cw)), dim3(256), lds, s, buf, H, W, C, cw);
+        // 512 lanes: a slab's H * W * cw / 8 items (400 .. 1600 at a 640 net) take half the rounds of each of the three
+        // barrier-separated passes, and the one workgroup a CU holds (LDS) puts two waves on every SIMD instead of one
+        hipLaunchKernelGGL(sppf_pool_lds_kernel, dim3(batch * (C / cw)), dim3(512), lds, s, buf, H, W, C, cw);
         return;
     }
     const int total = batch * H * W * (C >> 3);

@@ -554,6 +554,17 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         if (tid < kMatW) s_keptw[tid] = 0ull;
         __syncthreads();
         const int nw = (n + 63) >> 6;
+        // per class and 64-candidate word: which candidates have that class (one ballot per class and wave) -- the class
+        // filter of the matrix rows below is then ONE 8-byte LDS read per word instead of sixteen 16-byte ones
+        __shared__ unsigned long long s_clsmask[16][kMatW];
+        if (wave < kMatW) {
+            const int c = tid < (nw << 6) ? ccls[tid] : -1;
+            for (int k = 0; k < a.nc; k++) {
+                const unsigned long long mk = __ballot(c == k);
+                if (lane == 0) s_clsmask[k][wave] = mk;
+            }
+        }
+        __syncthreads();
         for (int item = tid; item < n * nw; item += blockDim.x) {
             const int w = item / n, i = item - w * n;          // consecutive lanes: consecutive i, same word -> broadcast reads of j
             unsigned long long mask = 0ull;
@@ -562,14 +573,8 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
                 const f32x4 bi = cbox[i];
                 const int ci = ccls[i];
                 const int jend = i - j0 < 64 ? i - j0 : 64;
-                // class filter first, 4 candidates per LDS read (all lanes of a wave read the same words: broadcast), then the
-                // IoU test only for the few same-class candidates
-                unsigned long long same = 0ull;
-#pragma unroll
-                for (int jj = 0; jj < 64; jj += 4) {
-                    const int4 c4 = *reinterpret_cast<const int4 *>(&ccls[j0 + jj]);
-                    same |= (unsigned long long)((c4.x == ci) | ((c4.y == ci) << 1) | ((c4.z == ci) << 2) | ((c4.w == ci) << 3)) << jj;
-                }
+                // class filter first (the per-class word built above), then the IoU test only for the few same-class candidates
+                unsigned long long same = s_clsmask[ci][w];
                 if (jend < 64) same &= (1ull << jend) - 1ull;
                 while (same) {
                     const int jj = __ffsll((long long)same) - 1;
