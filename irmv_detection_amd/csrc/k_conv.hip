@@ -454,14 +454,21 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
 #pragma unroll
         for (int i = 0; i < 8; i++) bias[u][i] = a.bias[(nblk * 2 + u) * 32 + g * 8 + i];
 
-    // pixel tile t of this wave: source pointers of both K segments for its two 16-pixel halves
+    // This wave's share of the image: a CONTIGUOUS range of 16-pixel units, the same number for every wave of the launch
+    // give or take one (a fixed stride of 32-pixel tiles left a quarter of the waves with a fourth tile where the others
+    // had three: the launch lasted as long as they did).  The range is walked in 32-pixel tiles; an odd unit at its end
+    // is a half tile with its own copy of the tile body (MT = 1: no loads, MFMAs or epilogue for the missing half).
+    const int units = (a.M + 15) >> 4, nw = wg_per_nblock * 4, wv = blockIdx.x * 4 + wave;
+    const int u0 = (int)((long long)wv * units / nw), u1 = (int)((long long)(wv + 1) * units / nw);
+    (void)tiles_total;
+    // unit ub .. ub + MT - 1: source pointers of both K segments (a unit past this wave's range reads pixel 0: never stored)
     const half_t *p0[MT], *p1[MT];
     bool mv[MT];
-    auto tile_ptrs = [&](int t) {
+    auto tile_ptrs = [&](int ub) {
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const int m = (t * MT + mt) * 16 + r;
-            mv[mt] = t < tiles_total && m < a.M;
+            const int m = (ub + mt) * 16 + r;
+            mv[mt] = ub + mt < u1 && m < a.M;
             const int mm = mv[mt] ? m : 0;
             const int b = mm / HWo, rem = mm - b * HWo;
             const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
@@ -478,10 +485,8 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
         return *reinterpret_cast<const half8 *>((c < a.s0.C ? p0[mt] : p1[mt]) + c);
     };
 
-    const int stride = wg_per_nblock * 4;
-    int t = blockIdx.x * 4 + wave;
     half8 B[MT][KS];
-    tile_ptrs(t);
+    tile_ptrs(u0);
 #pragma unroll
     for (int ks = 0; ks < KS; ks++)
 #pragma unroll
@@ -490,15 +495,18 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
     for (int i = 0; i < KS; i++) s_w[tid + i * 256] = wreg[i];
     __syncthreads();                                             // weights staged
     half_t *out = static_cast<half_t *>(a.out);
-    while (t < tiles_total) {
-        size_t m_cur[MT];
-        bool mv_cur[MT];
+    // one tile: MTA active 16-pixel units; PRE: re-load every consumed fragment for the tile that follows
+    auto run_tile = [&](auto mta_c, auto pre_c, int ub) {
+        constexpr int MTA = decltype(mta_c)::value;
+        constexpr bool PRE = decltype(pre_c)::value;
+        size_t m_cur[MTA];
+        bool mv_cur[MTA];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) { m_cur[mt] = (size_t)(t * MT + mt) * 16 + r; mv_cur[mt] = mv[mt]; }
-        tile_ptrs(t + stride);                                   // from here p0 / p1 / mv describe the NEXT tile
-        f32x4 acc[MT][NT];
+        for (int mt = 0; mt < MTA; mt++) { m_cur[mt] = (size_t)(ub + mt) * 16 + r; mv_cur[mt] = mv[mt]; }
+        if constexpr (PRE) tile_ptrs(ub + MT);                   // from here p0 / p1 / mv describe the NEXT tile
+        f32x4 acc[MTA][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int mt = 0; mt < MTA; mt++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // A fragments from LDS, double-buffered one k-step ahead; the scheduling barrier keeps the compiler from hoisting
@@ -513,16 +521,16 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
                 for (int nt = 0; nt < NT; nt++) A[(ks + 1) & 1][nt] = s_w[(nt * KS + ks + 1) * 64 + lane];
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
+            for (int mt = 0; mt < MTA; mt++) {
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks & 1][nt], B[mt][ks], acc[mt][nt], 0, 0, 0);
-                B[mt][ks] = load_b(mt, ks);                      // consumed: fetch the next tile's fragment into the same registers
+                if constexpr (PRE) B[mt][ks] = load_b(mt, ks);   // consumed: fetch the next tile's fragment into the same registers
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue of the direct kernel's paired-tile path: lane g holds channels u * 32 + g * 8 + [0, 8) of its pixel
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
+        for (int mt = 0; mt < MTA; mt++) {
             if (!mv_cur[mt]) continue;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -538,8 +546,10 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
                 *reinterpret_cast<half8 *>(out + m_cur[mt] * a.out_ld + (nblk * 2 + u) * 32 + g * 8) = o;
             }
         }
-        t += stride;
-    }
+    };
+    int ub = u0;
+    for (; ub + MT <= u1; ub += MT) run_tile(std::integral_constant<int, MT>{}, std::true_type{}, ub);
+    if (ub < u1) run_tile(std::integral_constant<int, 1>{}, std::false_type{}, ub);
 }
 
 // eligible: 1x1, SiLU, fp16 out, pair-packed, 64 | cout, K a multiple of 32 with 4..16 k-steps, first segment a multiple of 32
