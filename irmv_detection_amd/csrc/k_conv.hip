@@ -93,7 +93,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, int wg_x, int 
     const half8 *wp = reinterpret_cast<const half8 *>(a.w) + (size_t)nt0 * a.ksteps * 64 + lane;
     const int H0 = a.Hin >> a.s0.shift, W0 = a.Win >> a.s0.shift;
     const int H1 = a.Hin >> a.s1.shift, W1 = a.Win >> a.s1.shift;
-    const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 
     // ---- loader state: walks the k-steps in order, PF steps ahead of the MFMAs ----
     int l_ks = 0, l_tap = 0, l_cc = 0;
@@ -447,7 +446,6 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
     }
     const int HWo = a.Hout * a.Wout;
     const int H0 = a.Hin >> a.s0.shift, W0 = a.Win >> a.s0.shift, H1 = a.Hin >> a.s1.shift, W1 = a.Win >> a.s1.shift;
-    const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
     float bias[2][8];
 #pragma unroll
     for (int u = 0; u < 2; u++)
