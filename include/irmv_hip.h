@@ -206,6 +206,10 @@ int irmv_engine_read_input(irmv_engine *e, int slot, float *chw);             /*
 int irmv_engine_read_head(irmv_engine *e, int slot, float *head);             /* [anchors][64+nc+nk] */
 int irmv_engine_write_head(irmv_engine *e, int slot, const float *head);      /* inject a head tensor ... */
 int irmv_engine_run_post(irmv_engine *e, int first_slot, int count);          /* ... and run decode->NMS->PnP only */
+/* fault injection for the robustness test: overwrite every slot's candidate counter (the one piece of state a step leaves for
+ * the next kernel of the same step) with `value`.  The next step must stay inside its buffers and reset the counter; the
+ * step after it must be correct again.  IRMV_ERR_ARG for an engine that keeps no counters (IRMV_SPLIT_SCAN=0). */
+int irmv_engine_debug_poke_candidate_counts(irmv_engine *e, int value);
 int irmv_engine_read_tap(irmv_engine *e, int slot, const char *name, float *nhwc, int shape[3]);
 int irmv_engine_read_raw(irmv_engine *e, int slot, irmv_raw_dets *out);
 int irmv_engine_num_anchors(const irmv_engine *e);

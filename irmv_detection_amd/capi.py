@@ -98,6 +98,7 @@ SYMBOLS = [
     ("irmv_engine_read_head", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     ("irmv_engine_write_head", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     ("irmv_engine_run_post", C.c_int, [_P, C.c_int, C.c_int]),
+    ("irmv_engine_debug_poke_candidate_counts", C.c_int, [_P, C.c_int]),
     ("irmv_engine_read_tap", C.c_int, [_P, C.c_int, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     ("irmv_engine_read_raw", C.c_int, [_P, C.c_int, C.POINTER(RawDets)]),
     ("irmv_engine_num_anchors", C.c_int, [_P]),

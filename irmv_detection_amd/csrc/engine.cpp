@@ -1959,6 +1959,17 @@ extern "C" int irmv_engine_submit(irmv_engine *e, int first, int count, uint32_t
 
 extern "C" int irmv_engine_wait(irmv_engine *e);
 
+extern "C" int irmv_engine_debug_poke_candidate_counts(irmv_engine *e, int value)
+{
+    if (!e) return fail(IRMV_ERR_ARG, "engine is null");
+    if (!e->cand_counts) return fail(IRMV_ERR_ARG, "this engine keeps no candidate counters");
+    TRY(irmv_engine_wait(e));
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    std::vector<int> v((size_t)e->cfg.num_slots, value);
+    HIP_TRY(hipMemcpy(e->cand_counts, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+    return IRMV_OK;
+}
+
 extern "C" int irmv_engine_run_post(irmv_engine *e, int first, int count)
 {
     TRY(check_range(e, first, count));

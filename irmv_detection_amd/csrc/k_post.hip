@@ -50,6 +50,15 @@ __device__ __forceinline__ float unorderable(uint32_t u)
     return __uint_as_float(u);
 }
 
+// Anchor of a candidate key's id (= anchor * nc + class), CLAMPED to the head: keys are only ever written with valid ids, but
+// a key list read to a count that held garbage hands stale bytes to every later phase, and none of
+// them may turn that into an access outside a buffer.
+__device__ __forceinline__ int anchor_of(uint32_t id, int nc, int A)
+{
+    const uint32_t an = id / (uint32_t)nc;
+    return an < (uint32_t)A ? (int)an : A - 1;
+}
+
 // anchor -> grid position, stride, and the (level base, level size, index in level) that locate its head record
 __device__ __forceinline__ void anchor_geom(int a, int net, int &ix, int &iy, int &stride, int &lbase, int &lhw, int &rin)
 {
@@ -382,8 +391,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
                 const bool live = ci < n;                          // quad-uniform
                 const unsigned long long key = live ? (n <= kCandCap ? skeys[ci] : gk[ci]) : 0ull;
                 const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
-                int an = live ? (int)(id / (uint32_t)a.nc) : 0;
-                an = an < a.A ? an : 0;                            // (a key list holding garbage cannot push an access outside the head)
+                const int an = live ? anchor_of(id, a.nc, a.A) : 0;
                 int ix, iy, st, lbase, lhw, rin;
                 anchor_geom(an, a.net, ix, iy, st, lbase, lhw, rin);
                 const float *rec = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         for (int i = tid; i < ((n + 63) & ~63); i += blockDim.x) {
             if (i < n) {
                 const uint32_t id = 0xffffffffu - (uint32_t)(sorted[i] & 0xffffffffu);
-                cbox[i] = boxes[(int)(id / (uint32_t)a.nc)];
+                cbox[i] = boxes[anchor_of(id, a.nc, a.A)];
                 ccls[i] = (int)(id % (uint32_t)a.nc);
             } else {
                 ccls[i] = -1;      // padding up to the block boundary: no class
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         const bool valid = idx < n;
         const unsigned long long key = valid ? sorted[idx] : 0ull;
         const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
-        const int an = valid ? (int)(id / (uint32_t)a.nc) : 0;
+        const int an = valid ? anchor_of(id, a.nc, a.A) : 0;
         const int cls = valid ? (int)(id % (uint32_t)a.nc) : -1;
         const f32x4 box = valid ? boxes[an] : (f32x4){0.f, 0.f, 0.f, 0.f};
         ssup[idx] = block_sup_mask(box, cls, lane, a.iou_thr, stage_box[wave], stage_cls[wave]);
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             const bool valid = idx < n;
             const unsigned long long key = valid ? sorted[idx] : 0ull;
             const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
-            const int an = valid ? (int)(id / (uint32_t)a.nc) : 0;
+            const int an = valid ? anchor_of(id, a.nc, a.A) : 0;
             const int cls = valid ? (int)(id % (uint32_t)a.nc) : -1;
             const f32x4 box = valid ? boxes[an] : (f32x4){0.f, 0.f, 0.f, 0.f};
             // against the kept boxes of my class
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             const f32x4 box = kept_box[j];
             const unsigned long long key = kept_key[j];
             const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
-            const int an = (int)(id / (uint32_t)a.nc);
+            const int an = anchor_of(id, a.nc, a.A);
             const float logit = unorderable((uint32_t)(key >> 32));
             d.score = 1.0f / (1.0f + irmv_expf(-logit));
             d.cls = kept_cls[j];

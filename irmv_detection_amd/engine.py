@@ -299,6 +299,10 @@ class YoloEngine:
                     classes=classes[:n], anchors=anchors[:n], kpts=kpts[:n],
                     boxes_padded=boxes, scores_padded=scores)
 
+    def debug_poke_candidate_counts(self, value: int) -> None:
+        """Fault injection (tests): overwrite every slot's candidate counter."""
+        capi.check(self._L.irmv_engine_debug_poke_candidate_counts(self._h, int(value)))
+
     def profile(self, first_slot: int = 0, count: Optional[int] = None) -> List[dict]:
         count = self.num_slots - first_slot if count is None else count
         stats = (capi.KernelStat * 256)()

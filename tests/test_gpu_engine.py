@@ -467,6 +467,31 @@ def test_grouped_detect_launches_are_bitwise_the_separate_convs(blob, monkeypatc
     monkeypatch.delenv("IRMV_GROUP_HEAD")
 
 
+def test_a_garbage_candidate_counter_costs_one_step_and_no_fault(blob):
+    """Round 1's GPU memory fault was a kernel trusting a per-frame counter that held garbage.  The counter exists again
+    (candidates are appended by the class-branch conv epilogues): whatever it holds when a step starts, that step stays
+    inside its buffers and resets it, and the following step is correct -- single-frame engines and batched steps."""
+    for slots in (1, 4):
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=slots) as e:
+            for s in range(slots):
+                _load(e, s, frames.synthetic_frame(s))
+            e.submit(0, slots)
+            e.wait()
+            want = [e.read_raw(s) for s in range(slots)]
+            assert all(w["num_dets"] > 0 for w in want)
+            for value in (0x7FFFFFFF, -7, 50000, 8400 * 14 + 5, 1):
+                e.debug_poke_candidate_counts(value)
+                e.submit(0, slots)            # may report anything -- but must neither fault nor leave the counter dirty
+                e.wait()
+                e.submit(0, slots)
+                e.wait()
+                for s in range(slots):
+                    got = e.read_raw(s)
+                    assert got["n_candidates"] == want[s]["n_candidates"] and got["num_dets"] == want[s]["num_dets"], (slots, value, s)
+                    assert np.array_equal(got["boxes"], want[s]["boxes"]) and np.array_equal(got["anchors"], want[s]["anchors"])
+                    assert np.array_equal(got["kpts"], want[s]["kpts"])
+
+
 def _bench_tune_cache(tmp_path, monkeypatch):
     """Seed the autotuner exactly as bench.py does (its own copy of profiles/*_tune_cache.txt)."""
     import os, shutil
