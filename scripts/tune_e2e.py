@@ -1,0 +1,109 @@
+"""End-to-end refinement of the autotuner's table: the per-layer autotuner times every conv ALONE, but the benchmarked step
+replays two 64-frame graphs concurrently, where a tile's footprint (LDS, registers, workgroups) also decides how well it
+shares the chip with the other graph's kernels -- a tile that is 5 % slower alone can be 2 % faster in the step.
+Coordinate descent over the heavy batched (n64) entries of a table, the objective being bench.py's own FPS; every tile it
+may pick is one the engine offers for that layer and all of them are bitwise neutral (the engine re-tunes an entry it does
+not accept).  Run on the GPU box:  python3 scripts/tune_e2e.py <in table> <out table> [budget seconds]"""
+import json, os, re, shutil, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = sys.argv[1], sys.argv[2]
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else 900.0
+t_start = time.time()
+log = open(os.path.join(ROOT, "gpurun_out", "tune_e2e.log"), "a")
+
+
+def say(*a):
+    print(*a, file=log, flush=True)
+    print(*a, flush=True)
+
+
+def parse(path):
+    out = []
+    for ln in open(path):
+        ln = ln.rstrip("\n")
+        if not ln:
+            continue
+        key, val = ln.rsplit("|", 1)
+        out.append([key, [int(v) for v in val.split()]])      # [suffix, mt, nt, flags, ipw]
+    return out
+
+
+def write(path, entries):
+    with open(path, "w") as f:
+        for k, v in entries:
+            f.write(k + "|" + " ".join(str(x) for x in v) + "\n")
+
+
+def evaluate(entries, steps=120):
+    tmp = "/tmp/tune_e2e_cache.txt"
+    write(tmp, entries)
+    env = dict(os.environ, IRMV_TUNE_CACHE=tmp, IRMV_BENCH_SKIP="latency,h2d")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "10", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{"):
+            return json.loads(ln)["value"]
+    raise RuntimeError(p.stderr[-400:])
+
+
+entries = parse(src)
+idx = {i: e for i, e in enumerate(entries)}
+
+
+def candidates(key, v):
+    m = re.match(r"gfx950\|(\d)\.(\d)\.(\d)\.(\d)\.(\d)\.(\d)\|(\d+)x\d+>(\d+)x\d+\|c(\d+)\.(\d+)\.\d\.\d>(\d+)\|.*\|n(\d+)$", key)
+    ks, stride, cin16, act, f32, ldsfam, hin, hout, c0, c1, cout, n = (int(x) for x in m.groups())
+    suffix, mt, nt, flags, ipw = v
+    fused = suffix >= 2                      # a 1x1 rides in the epilogue: nt stays 4
+    out = []
+    if n != 64:
+        return out
+    if ks == 3 and ldsfam and not cin16 and act == 1:
+        nts = [4] if (fused or cout % 64 == 0) else [nt]
+        if not fused and cout % 64 == 0:
+            nts = [4, 2]
+        for a in ([1] if stride == 2 else [4, 2, 1]):
+            for b in nts:
+                for c in (4, 2, 1):
+                    out.append([suffix, a, b, 1, c])
+    elif ks == 1 and act == 1 and not f32 and cout % 64 == 0:
+        out = [[suffix, 2, 4, 8, 1], [suffix, 2, 4, 0, 1], [suffix, 4, 4, 0, 1]]
+    return [c for c in out if c != v]
+
+
+# heavy entries first: 80x80 and stride-2 3x3s, then 40x40, then the 1x1s, then 20x20
+def weight(key):
+    m = re.match(r"gfx950\|(\d)\.(\d).*\|(\d+)x\d+>(\d+)x", key)
+    ks, stride, hin, hout = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4))
+    return -(hout * hout * (9 if ks == 3 else 2) * (2 if stride == 2 else 1))
+
+
+order = sorted((i for i, (k, v) in idx.items() if candidates(k, v)), key=lambda i: weight(entries[i][0]))
+base = (evaluate(entries) + evaluate(entries)) / 2
+say(f"baseline {base:.0f} FPS; {len(order)} entries to visit")
+best = base
+for i in order:
+    k, v = entries[i]
+    for c in candidates(k, v):
+        if time.time() - t_start > budget:
+            break
+        trial = [e if j != i else [k, c] for j, e in enumerate(entries)]
+        try:
+            f1 = evaluate(trial)
+        except Exception as ex:
+            say("  eval failed", k.split("|", 2)[2], c, str(ex)[:100])
+            continue
+        if f1 > best * 1.005:
+            f2 = evaluate(trial)
+            f = (f1 + f2) / 2
+            say(f"  {k.split('|', 2)[2]}  {v[1:]} -> {c[1:]}: {f1:.0f} / {f2:.0f} vs {best:.0f}", "ACCEPT" if f > best * 1.004 else "no")
+            if f > best * 1.004:
+                entries, best, v = trial, f, c
+        else:
+            say(f"  {k.split('|', 2)[2]}  {v[1:]} -> {c[1:]}: {f1:.0f} vs {best:.0f}")
+    if time.time() - t_start > budget:
+        say("budget reached")
+        break
+final = (evaluate(entries) + evaluate(entries)) / 2
+say(f"final {final:.0f} FPS (baseline {base:.0f})")
+write(dst, entries)
