@@ -32,37 +32,61 @@ constexpr int C0HALF = (C0W + 1) / 2;                // columns per parity plane
 constexpr int INH = 4 * TY + 3, INW = 4 * TX + 3;    // net-input pixels those need
 constexpr int MTC = TY / 4;                          // model.1 output rows per wave
 constexpr int INP = INW + 1;                         // row pitch (pixels); the extra column stays zero
+#ifndef IRMV_FRONT_BT
+#define IRMV_FRONT_BT 2
+#endif
+#ifndef IRMV_FRONT_A1_LATE
+#define IRMV_FRONT_A1_LATE 0
+#endif
+#ifndef IRMV_FRONT_WAVES
+#define IRMV_FRONT_WAVES 5
+#endif
 }  // namespace
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void front_kernel(FrontArgs a)   // 5 waves per SIMD = 96 VGPRs: the occupancy step the kernel sat on before its biases moved to LDS
+#if IRMV_FSTAMP
+__device__ unsigned long long g_front_stamps[65536 * 9];   // probe builds: shader-clock stamps of the phase boundaries, wave 0 of every workgroup
+#define FSTAMP(k) do { if (tid == 0) { fst[k] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define FSTAMP(k)
+#endif
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_WAVES))) void front_kernel(FrontArgs a)   // 5 waves per SIMD = 96 VGPRs: the occupancy step the kernel sat on before its biases moved to LDS
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // a.stage_bytes: source region, later model.0's tile
     __shared__ __attribute__((aligned(16))) half4 s_in[INH * INP];
     __shared__ uint32_t s_tx[INW], s_ty[INH];   // packed region-relative taps
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
+#if IRMV_FSTAMP
+    unsigned long long fst[10];
+#endif
+    FSTAMP(0);
     const int b = blockIdx.y;
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
     const int oy0 = tyi * TY, ox0 = txi * TX;
     const int net = a.net, W0 = net >> 1, W1 = net >> 2;
     const int gy0 = 4 * oy0 - 3, gx0 = 4 * ox0 - 3;   // net-input coordinates of s_in[0][0]
 
-    // both biases -> LDS now (visible after the staging barrier): fetched from global memory where they are used (start of
+    // both biases -> LDS (visible after the staging barrier): fetched from global memory where they are used (start of
     // stage B, epilogue of stage C) each exposes a memory round trip of a ~10 us workgroup; held in registers from here
-    // they cost the occupancy step this kernel sits on (measured +10 %)
+    // they cost the occupancy step this kernel sits on (measured +10 %).  Loaded now, stored behind the source loads:
+    // nothing in front of those loads may wait for memory (phase stamps: 34 % of a workgroup's life was the time before them)
     __shared__ float s_bias[16 + 32];
-    if (tid < 16) s_bias[tid] = a.b0[tid];
-    else if (tid < 48) s_bias[tid] = a.b1[tid - 16];
+    float bias_v = 0.f;
+    if (tid < 16) bias_v = a.b0[tid];
+    else if (tid < 48) bias_v = a.b1[tid - 16];
 
     // model.1 weights (5 k-steps x 2 tiles) and model.0 weights (2 k-steps) into registers early
     half8 A1[5][2];
-    {
-        const half8 *wp = reinterpret_cast<const half8 *>(a.w1) + lane;
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int ks = 0; ks < 5; ks++) A1[ks][nt] = wp[(size_t)(nt * 5 + ks) * 64];
+#define IRMV_FRONT_LOAD_A1()                                                                      \
+    {                                                                                             \
+        const half8 *wp = reinterpret_cast<const half8 *>(a.w1) + lane;                           \
+        _Pragma("unroll") for (int nt = 0; nt < 2; nt++)                                          \
+            _Pragma("unroll") for (int ks = 0; ks < 5; ks++) A1[ks][nt] = wp[(size_t)(nt * 5 + ks) * 64]; \
     }
+#if !IRMV_FRONT_A1_LATE
+    IRMV_FRONT_LOAD_A1()
+#endif
     const half8 *wp0 = reinterpret_cast<const half8 *>(a.w0) + lane;
     const half8 A00 = wp0[0], A01 = wp0[64];
 
@@ -81,17 +105,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         sy_max = max(max(ya.i0, ya.i1), max(yb.i0, yb.i1));
     }
     const int pitch = x1 - x0;                                       // staged pixels per row (4 bytes each)
-    // taps relative to the region, one dword each: i0 | i1 << 10 | w << 20 (w <= 2048); all ones = outside / padding
+    // this lane's tap (lanes 0 .. INW + INH - 1: one column or row of the tile each); packed and stored behind the source loads
+    AxisTap my_tap = AxisTap{-1, -1, 0, 0};
+    const bool tap_x = tid < INW;
     if (tid < INW + INH) {
-        const bool is_x = tid < INW;
-        const int i = is_x ? gx0 + tid : gy0 + (tid - INW);
-        AxisTap t = AxisTap{-1, -1, 0, 0};
-        if ((unsigned)i < (unsigned)net) t = is_x ? a.tx[i] : a.ty[i];
-        const int base = is_x ? x0 : sy_min;
-        const uint32_t pk = t.i0 < 0 ? 0xffffffffu : (uint32_t)(t.i0 - base) | ((uint32_t)(t.i1 - base) << 10) | ((uint32_t)t.w1 << 20);
-        if (is_x) s_tx[tid] = pk; else s_ty[tid - INW] = pk;
+        const int i = tap_x ? gx0 + tid : gy0 + (tid - INW);
+        if ((unsigned)i < (unsigned)net) my_tap = tap_x ? a.tx[i] : a.ty[i];
     }
 
+    FSTAMP(1);
     // ---- A1: source region -> LDS as 4-byte pixels (12 source bytes -> one 16-byte LDS store) ----
     uint32_t *s_px = reinterpret_cast<uint32_t *>(s_stage);
     if (any_src) {
@@ -101,40 +123,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         // All loads of a pass are issued before its first LDS store: a thread owns ~5 groups of the reference geometry
         // (33 rows x 35 groups / 256 threads), and one group per loop trip meant ~5 exposed memory round trips per
         // workgroup -- of a ~10 us workgroup lifetime.  CH = 6 groups per pass: one round trip for 1280 x 1024 -> 640.
+        // The kernel is bound by its vector-instruction issue (profiles/r02_mfma.json: VALU busy ~100 %), so the walk
+        // costs no division per group: group i sits at LDS dword 4 i and at source byte row(i) * skip + 12 i, and
+        // row(i + 256) follows from row(i) with one compare.
         constexpr int CH = 6;
         const float inv_gpr = 1.0f / (float)gpr;
+        int dq = (int)(256.0f * inv_gpr);                         // 256 = dq * gpr + dr (uniform)
+        dq -= (dq * gpr > 256) ? 1 : 0;
+        dq += ((dq + 1) * gpr <= 256) ? 1 : 0;
+        const int dr = 256 - dq * gpr;
+        int row = (int)((float)tid * inv_gpr);                    // tid < 2^15: one correction step makes the quotient exact
+        row -= (row * gpr > tid) ? 1 : 0;
+        row += ((row + 1) * gpr <= tid) ? 1 : 0;
+        int col = tid - row * gpr;
+        const uint32_t skip = (uint32_t)(row_bytes - (size_t)gpr * 12);
         for (int i0 = 0; i0 < total; i0 += 256 * CH) {
             uint32_t d0[CH], d1[CH], d2[CH];
-            int dst[CH];
 #pragma unroll
             for (int c = 0; c < CH; c++) {
                 const int i = i0 + c * 256 + tid;
-                dst[c] = -1;
                 d0[c] = d1[c] = d2[c] = 0u;
                 if (i < total) {
-                    int row = (int)((float)i * inv_gpr);          // i < 2^15: one correction step makes the quotient exact
-                    row -= (row * gpr > i) ? 1 : 0;
-                    row += ((row + 1) * gpr <= i) ? 1 : 0;
-                    const int gq = i - row * gpr;
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)row * row_bytes + (size_t)gq * 12);
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(src + ((uint32_t)row * skip + (uint32_t)i * 12u));
+#if defined(IRMV_FABL) && (IRMV_FABL & 1)
+                    d0[c] = (uint32_t)i; d1[c] = (uint32_t)row; d2[c] = (uint32_t)col; (void)q;
+#else
                     d0[c] = q[0]; d1[c] = q[1]; d2[c] = q[2];
-                    dst[c] = row * pitch + gq * 4;
+#endif
                 }
+                col += dr; row += dq;
+                if (col >= gpr) { col -= gpr; row++; }
             }
 #pragma unroll
             for (int c = 0; c < CH; c++) {
-                if (dst[c] >= 0) {
+                const int i = i0 + c * 256 + tid;
+                if (i < total) {
                     uint4 o;
                     o.x = d0[c] & 0xffffffu;
                     o.y = (d0[c] >> 24) | ((d1[c] & 0xffffu) << 8);
                     o.z = (d1[c] >> 16) | ((d2[c] & 0xffu) << 16);
                     o.w = d2[c] >> 8;
-                    *reinterpret_cast<uint4 *>(s_px + dst[c]) = o;
+                    *reinterpret_cast<uint4 *>(s_px + 4 * i) = o;
                 }
             }
         }
     }
+    // taps relative to the region, one dword each: i0 | i1 << 10 | w << 20 (w <= 2048); all ones = outside / padding
+    if (tid < INW + INH) {
+        const int base = tap_x ? x0 : sy_min;
+        const uint32_t pk = my_tap.i0 < 0 ? 0xffffffffu : (uint32_t)(my_tap.i0 - base) | ((uint32_t)(my_tap.i1 - base) << 10) | ((uint32_t)my_tap.w1 << 20);
+        if (tap_x) s_tx[tid] = pk; else s_ty[tid - INW] = pk;
+    }
+    if (tid < 48) s_bias[tid] = bias_v;
+    FSTAMP(2);
     __syncthreads();
+    FSTAMP(3);
 
     // ---- A2: bilinear resample into the NHWC4 tile (arithmetic of preprocess_kernel) ----
     {
@@ -142,6 +185,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         const float inv255 = 1.0f / 255.0f;   // (half)(q * inv255) == (half)(q / 255.0f) for every q in 0..255 (tests/test_oracle_preprocess.py)
         if (tid < INH) s_in[tid * INP + INW] = (half4){0, 0, 0, 0};   // the extra column of every row stays zero
         // 19 x 67 = 1273 pixels = five trips of 256 lanes (walking the padded 19 x 68 grid would need a sixth for 12 pixels)
+#if defined(IRMV_FABL) && (IRMV_FABL & 2)
+        if (a.fastx) {
+            for (int pp = tid; pp < INH * INW; pp += 256) {
+                const int ly = pp / INW, lx = pp - ly * INW;
+#if IRMV_FABL & 4096
+                if (a.net == 12345)
+#endif
+                s_in[ly * INP + lx] = (half4){padv, padv, padv, (half_t)0.0f};
+            }
+        } else
+#endif
+        if (a.fastx) {
+            // Columns at exactly 2 : 1 (every x tap = (2 k, 2 k + 1) with weight 1/2: 1280 -> 640): the horizontal blend
+            // of a channel is 1024 (p0 + p1), so with s = p0 + p1 of the two tap rows the fixed-point result
+            // ((2048 - wy) 1024 s0 + wy 1024 s1 + 2^21) >> 22 is ((2048 - wy) s0 + wy s1 + 2^11) >> 12 -- the same integer.
+            // The pair of a row is one aligned 8-byte LDS read; red / blue are summed side by side in one register.
+            const int xbase = a.fx_i0 + 2 * (gx0 - a.vx0) - x0;   // region-relative tap of lx = 0 (even: x0 and fx_i0 are)
+            auto blend = [&](int ly, int lx, uint32_t ty) -> half4 {
+                const int xa = xbase + 2 * lx;
+                const uint2 q0 = *reinterpret_cast<const uint2 *>(s_px + __umul24(ty & 1023u, pitch) + xa);
+                const uint2 q1 = *reinterpret_cast<const uint2 *>(s_px + __umul24((ty >> 10) & 1023u, pitch) + xa);
+                const uint32_t wy = ty >> 20, wy0 = kCoefOne - wy;
+                const uint32_t rb0 = (q0.x & 0x00ff00ffu) + (q0.y & 0x00ff00ffu), rb1 = (q1.x & 0x00ff00ffu) + (q1.y & 0x00ff00ffu);
+                const uint32_t g0 = ((q0.x >> 8) & 255u) + ((q0.y >> 8) & 255u), g1 = ((q1.x >> 8) & 255u) + ((q1.y >> 8) & 255u);
+                const uint32_t rnd = 1u << (kCoefBits);
+                const uint32_t c0 = (__umul24(wy0, rb0 & 0xffffu) + __umul24(wy, rb1 & 0xffffu) + rnd) >> (kCoefBits + 1);
+                const uint32_t c1 = (__umul24(wy0, g0) + __umul24(wy, g1) + rnd) >> (kCoefBits + 1);
+                const uint32_t c2 = (__umul24(wy0, rb0 >> 16) + __umul24(wy, rb1 >> 16) + rnd) >> (kCoefBits + 1);
+                half_t v0 = (half_t)((float)c0 * inv255), v1 = (half_t)((float)c1 * inv255), v2 = (half_t)((float)c2 * inv255);
+                if (a.swap_rb) { const half_t t = v0; v0 = v2; v2 = t; }
+                return (half4){v0, v1, v2, (half_t)0.0f};
+            };
+            // pixel tid + 256 k sits 3 rows and 55 columns (256 = 3 INW + 55) past pixel tid + 256 (k - 1)
+            static_assert(INW == 67 && INH * INW <= 5 * 256, "the walk below is written for the 19 x 67 tile");
+            int ly = tid / INW, lx = tid - ly * INW;
+            const bool inside = gx0 >= max(a.vx0, 0) && gx0 + INW <= min(a.vx1, net) && gy0 >= max(a.vy0, 0) && gy0 + INH <= min(a.vy1, net);
+            if (inside) {   // (three tiles in four) every pixel of the tile has both taps: nothing to test per pixel
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    if (k < 4 || tid < INH * INW - 4 * 256) s_in[ly * INP + lx] = blend(ly, lx, s_ty[ly]);
+                    lx += 256 - 3 * INW; ly += 3;
+                    if (lx >= INW) { lx -= INW; ly++; }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    if (k < 4 || tid < INH * INW - 4 * 256) {
+                        const int gx = gx0 + lx;
+                        half4 o = (half4){0, 0, 0, 0};
+                        if ((unsigned)(gy0 + ly) < (unsigned)net && (unsigned)gx < (unsigned)net) {
+                            const uint32_t ty = s_ty[ly];
+                            o = (ty == 0xffffffffu || gx < a.vx0 || gx >= a.vx1) ? (half4){padv, padv, padv, (half_t)0.0f} : blend(ly, lx, ty);
+                        }
+                        s_in[ly * INP + lx] = o;
+                    }
+                    lx += 256 - 3 * INW; ly += 3;
+                    if (lx >= INW) { lx -= INW; ly++; }
+                }
+            }
+        } else {
 #pragma unroll 5
         for (int pp = tid; pp < INH * INW; pp += 256) {
             const int ly = pp / INW, lx = pp - ly * INW;
@@ -152,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
                 if (ty == 0xffffffffu || tx == 0xffffffffu) {
                     o = (half4){padv, padv, padv, (half_t)0.0f};
                 } else {
-                    const uint32_t *r0 = s_px + (ty & 1023u) * pitch, *r1 = s_px + ((ty >> 10) & 1023u) * pitch;
+                    const uint32_t *r0 = s_px + __umul24(ty & 1023u, pitch), *r1 = s_px + __umul24((ty >> 10) & 1023u, pitch);
                     const uint32_t xa = tx & 1023u, xb = (tx >> 10) & 1023u;
                     const uint32_t wx = tx >> 20, wy = ty >> 20;
                     const uint32_t q00 = r0[xa], q01 = r0[xb], q10 = r1[xa], q11 = r1[xb];
@@ -173,8 +276,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
             }
             s_in[p] = o;
         }
+        }
     }
+    FSTAMP(4);
     __syncthreads();
+    FSTAMP(5);
 
     // ---- B: model.0.conv on the tile: 17 x 33 output pixels, 16 channels, K = [kh][4 tap slots][4 ch] ----
     // s_c0: parity-split columns ([row][column parity][column / 2][16 ch], 32 B per pixel): the stride-2
@@ -186,41 +292,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         float bias0[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) bias0[i] = s_bias[g * 4 + i];
-        for (int t = wave; t < NTILES; t += 4) {
-            const int m = t * 16 + r;
-            const bool mv = m < NPX;
-            const int mm = mv ? m : 0;
-            const int ly = mm / C0W, lx = mm - ly * C0W;
-            half8 bf[2];
+        // A tile is a chain LDS read -> two MFMAs -> SiLU -> LDS write; run one tile at a time it is the chain's LATENCY
+        // that a wave spends (ablation: the reads alone were 57 of the kernel's 182 us per 64 frames), so the wave's
+        // tiles go in batches: every fragment read of a batch is issued first, then its MFMAs, then its epilogues.
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const bool c0_inside = 2 * oy0 - 1 >= 0 && 2 * oy0 - 1 + C0H <= W0 && 2 * ox0 - 1 >= 0 && 2 * ox0 - 1 + C0W <= W0;   // no model.1 padding in this tile
+        constexpr int KT = (NTILES + 3) / 4;   // tiles per wave (the last one may not exist for the upper waves)
+        constexpr int BT = IRMV_FRONT_BT;
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const int kh = 2 * s + (g >> 1);
-                half4 lo = z4, hi = z4;
-                if (mv && kh < 3) {
-                    const half4 *q = s_in + (2 * ly + kh) * INP + 2 * lx + 2 * (g & 1);
-                    lo = q[0];
-                    if ((g & 1) == 0) hi = q[1];   // slot 3 is padding
+#if defined(IRMV_FABL) && (IRMV_FABL & 4)
+        for (int k0 = 0; k0 < 0; k0 += BT) {
+#else
+        for (int k0 = 0; k0 < KT; k0 += BT) {
+#endif
+            half8 bf[BT][2];
+            f32x4 acc[BT];
+            int lyv[BT], lxv[BT];
+            bool mvv[BT];
+#pragma unroll
+            for (int k = 0; k < BT; k++) {
+                if (k0 + k >= KT) continue;
+                const int m = (wave_u + 4 * (k0 + k)) * 16 + r;
+                mvv[k] = m < NPX;
+                const int mm = mvv[k] ? m : 0;
+                lyv[k] = mm / C0W;
+                lxv[k] = mm - lyv[k] * C0W;
+                // k slots without a tap (kernel row 3, tap slot 3) carry ZERO weights (engine.cpp packs them so), and s_in
+                // holds finite values only (pixels, padding, zeros; column INW of every row is zero): such a slot may read any
+                // pixel of the tile -- 0 x finite adds nothing -- so both halves of a fragment are ONE unpredicated 16-byte read
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const int kh = s == 0 ? (g >> 1) : 2;          // k-step 1: kernel row 2 (g < 2) / no tap (row 2 again)
+#if defined(IRMV_FABL) && (IRMV_FABL & 2048)
+                    bf[k][s] = A00; bf[k][s][0] = (half_t)(float)(lyv[k] + kh); bf[k][s][1] = (half_t)(float)lxv[k];
+                    if (a.net == 12345) bf[k][s] = *reinterpret_cast<const half8 *>(s_in + tid);   // keeps stage A2 alive
+#else
+                    bf[k][s] = *reinterpret_cast<const half8 *>(s_in + (2 * lyv[k] + kh) * INP + 2 * lxv[k] + 2 * (g & 1));
+#endif
                 }
-                bf[s] = (half8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A00, bf[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A01, bf[1], acc, 0, 0, 0);
-            if (mv) {
-                const int cy = 2 * oy0 - 1 + ly, cx = 2 * ox0 - 1 + lx;
-                half4 o = z4;
-                if ((unsigned)cy < (unsigned)W0 && (unsigned)cx < (unsigned)W0) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const float v = acc[i] + bias0[i];
-                        o[i] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
+            for (int k = 0; k < BT; k++) {
+                if (k0 + k >= KT) continue;
+#if defined(IRMV_FABL) && (IRMV_FABL & 512)
+                acc[k] = (f32x4){(float)bf[k][0][0], (float)bf[k][0][1], (float)bf[k][0][2], (float)bf[k][0][3]};
+#else
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A00, bf[k][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#endif
+            }
+#pragma unroll
+            for (int k = 0; k < BT; k++) {
+                if (k0 + k >= KT) continue;
+#if defined(IRMV_FABL) && (IRMV_FABL & 512)
+                acc[k][0] += (float)bf[k][1][0]; acc[k][1] += (float)bf[k][1][1];
+#else
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A01, bf[k][1], acc[k], 0, 0, 0);
+#endif
+            }
+#pragma unroll
+            for (int k = 0; k < BT; k++) {
+                if (k0 + k >= KT) continue;
+                if (mvv[k]) {
+                    const int ly = lyv[k], lx = lxv[k];
+                    const int cy = 2 * oy0 - 1 + ly, cx = 2 * ox0 - 1 + lx;
+                    half4 o = z4;
+                    if (c0_inside || ((unsigned)cy < (unsigned)W0 && (unsigned)cx < (unsigned)W0)) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const float v = acc[k][i] + bias0[i];
+#if defined(IRMV_FABL) && (IRMV_FABL & 256)
+                            o[i] = (half_t)v;
+#else
+                            o[i] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
+#endif
+                        }
                     }
+                    *reinterpret_cast<half4 *>(s_c0 + (size_t)((ly * 2 + (lx & 1)) * C0HALF + (lx >> 1)) * 16 + g * 4) = o;
                 }
-                *reinterpret_cast<half4 *>(s_c0 + (size_t)((ly * 2 + (lx & 1)) * C0HALF + (lx >> 1)) * 16 + g * 4) = o;
             }
         }
     }
+#if IRMV_FRONT_A1_LATE
+    IRMV_FRONT_LOAD_A1()   // (forty registers that stage B's batches need more: the loads ride under the barrier)
+#endif
+    FSTAMP(6);
     __syncthreads();
+    FSTAMP(7);
 
     // ---- C: model.1.conv: 8 x 16 outputs x 32 channels; Cin = 16, so a k-step of 32 spans two taps ----
     {
@@ -230,8 +387,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+#if defined(IRMV_FABL) && (IRMV_FABL & 8)
+        for (int ks = 0; ks < 0; ks++) {
+#else
 #pragma unroll
         for (int ks = 0; ks < 5; ks++) {
+#endif
             const int tap = 2 * ks + (g >> 1);
             const int kh = tap / 3, kw = tap - kh * 3;
             half8 B[MTC];
@@ -265,15 +426,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
                     vals[i] = acc[mt][0][i] + bias1[i];
                     vals[4 + i] = acc[mt][1][i] + bias1[4 + i];
                 }
+#if !(defined(IRMV_FABL) && (IRMV_FABL & 8))
 #pragma unroll
                 for (int i = 0; i < 8; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
+#endif
                 half8 o;
 #pragma unroll
                 for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
+#if defined(IRMV_FABL) && (IRMV_FABL & 64)
+                if (o[0] == (half_t)12345.0f)
+#endif
                 *reinterpret_cast<half8 *>(a.out + ((size_t)(b * W1 + oy) * W1 + ox) * a.out_ld + g * 8) = o;
             }
         }
     }
+#if IRMV_FSTAMP
+    FSTAMP(8);
+    if (tid == 0) {
+        const unsigned wg = (blockIdx.y * gridDim.x + blockIdx.x) & 65535u;
+        for (int k = 0; k < 9; k++) g_front_stamps[wg * 9 + k] = fst[k];
+    }
+#endif
 }
 
 int front_min_stage_bytes() { return C0H * 2 * C0HALF * 32; }
