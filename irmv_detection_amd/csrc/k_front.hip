@@ -32,15 +32,6 @@ constexpr int C0HALF = (C0W + 1) / 2;                // columns per parity plane
 constexpr int INH = 4 * TY + 3, INW = 4 * TX + 3;    // net-input pixels those need
 constexpr int MTC = TY / 4;                          // model.1 output rows per wave
 constexpr int INP = INW + 1;                         // row pitch (pixels); the extra column stays zero
-#ifndef IRMV_FRONT_BT
-#define IRMV_FRONT_BT 2
-#endif
-#ifndef IRMV_FRONT_A1_LATE
-#define IRMV_FRONT_A1_LATE 0
-#endif
-#ifndef IRMV_FRONT_WAVES
-#define IRMV_FRONT_WAVES 5
-#endif
 }  // namespace
 
 #if IRMV_FSTAMP
@@ -50,7 +41,7 @@ __device__ unsigned long long g_front_stamps[65536 * 9];   // probe builds: shad
 #define FSTAMP(k)
 #endif
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_WAVES))) void front_kernel(FrontArgs a)   // 5 waves per SIMD = 96 VGPRs: the occupancy step the kernel sat on before its biases moved to LDS
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void front_kernel(FrontArgs a)   // 5 waves per SIMD = 96 VGPRs: the occupancy step the kernel sat on before its biases moved to LDS
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // a.stage_bytes: source region, later model.0's tile
     __shared__ __attribute__((aligned(16))) half4 s_in[INH * INP];
@@ -78,15 +69,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
 
     // model.1 weights (5 k-steps x 2 tiles) and model.0 weights (2 k-steps) into registers early
     half8 A1[5][2];
-#define IRMV_FRONT_LOAD_A1()                                                                      \
-    {                                                                                             \
-        const half8 *wp = reinterpret_cast<const half8 *>(a.w1) + lane;                           \
-        _Pragma("unroll") for (int nt = 0; nt < 2; nt++)                                          \
-            _Pragma("unroll") for (int ks = 0; ks < 5; ks++) A1[ks][nt] = wp[(size_t)(nt * 5 + ks) * 64]; \
+    {
+        const half8 *wp = reinterpret_cast<const half8 *>(a.w1) + lane;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int ks = 0; ks < 5; ks++) A1[ks][nt] = wp[(size_t)(nt * 5 + ks) * 64];
     }
-#if !IRMV_FRONT_A1_LATE
-    IRMV_FRONT_LOAD_A1()
-#endif
     const half8 *wp0 = reinterpret_cast<const half8 *>(a.w0) + lane;
     const half8 A00 = wp0[0], A01 = wp0[64];
 
@@ -99,19 +88,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
     int x0 = 0, x1 = 0, sy_min = 0, sy_max = -1;
     if (any_src) {
         const AxisTap xa = a.tx[cx_lo], xb = a.tx[cx_hi], ya = a.ty[cy_lo], yb = a.ty[cy_hi];
-        x0 = min(min(xa.i0, xa.i1), min(xb.i0, xb.i1)) & ~3;           // the region starts on a 4-pixel (12-byte) group
-        x1 = min((max(max(xa.i0, xa.i1), max(xb.i0, xb.i1)) + 4) & ~3, a.sw);
-        sy_min = min(min(ya.i0, ya.i1), min(yb.i0, yb.i1));
-        sy_max = max(max(ya.i0, ya.i1), max(yb.i0, yb.i1));
+        // (min3 / max3 exist on the vector unit only: back to scalar registers, or everything derived from the box --
+        // the region's base address, its group count, the walk's steps -- is computed per lane)
+        x0 = __builtin_amdgcn_readfirstlane(min(min(xa.i0, xa.i1), min(xb.i0, xb.i1)) & ~3);   // the region starts on a 4-pixel (12-byte) group
+        x1 = __builtin_amdgcn_readfirstlane(min((max(max(xa.i0, xa.i1), max(xb.i0, xb.i1)) + 4) & ~3, a.sw));
+        sy_min = __builtin_amdgcn_readfirstlane(min(min(ya.i0, ya.i1), min(yb.i0, yb.i1)));
+        sy_max = __builtin_amdgcn_readfirstlane(max(max(ya.i0, ya.i1), max(yb.i0, yb.i1)));
     }
     const int pitch = x1 - x0;                                       // staged pixels per row (4 bytes each)
     // this lane's tap (lanes 0 .. INW + INH - 1: one column or row of the tile each); packed and stored behind the source loads
-    AxisTap my_tap = AxisTap{-1, -1, 0, 0};
+    // (loaded by EVERY lane from a clamped index and masked where it is used: a load under a branch is copied out of the
+    // branch's block behind a wait -- for every load issued so far -- in front of the source loads)
     const bool tap_x = tid < INW;
-    if (tid < INW + INH) {
-        const int i = tap_x ? gx0 + tid : gy0 + (tid - INW);
-        if ((unsigned)i < (unsigned)net) my_tap = tap_x ? a.tx[i] : a.ty[i];
-    }
+    const int tap_i = tap_x ? gx0 + tid : gy0 + (tid - INW);
+    const bool tap_ok = tid < INW + INH && (unsigned)tap_i < (unsigned)net;
+    AxisTap my_tap = (tap_x ? a.tx : a.ty)[min(max(tap_i, 0), net - 1)];
 
     FSTAMP(1);
     // ---- A1: source region -> LDS as 4-byte pixels (12 source bytes -> one 16-byte LDS store) ----
@@ -127,33 +118,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
         // costs no division per group: group i sits at LDS dword 4 i and at source byte row(i) * skip + 12 i, and
         // row(i + 256) follows from row(i) with one compare.
         constexpr int CH = 6;
-        const float inv_gpr = 1.0f / (float)gpr;
+        const float inv_gpr = __builtin_amdgcn_rcpf((float)gpr);   // (1 ulp: the correction steps below absorb it)
         int dq = (int)(256.0f * inv_gpr);                         // 256 = dq * gpr + dr (uniform)
         dq -= (dq * gpr > 256) ? 1 : 0;
         dq += ((dq + 1) * gpr <= 256) ? 1 : 0;
+        dq = __builtin_amdgcn_readfirstlane(dq);
         const int dr = 256 - dq * gpr;
         int row = (int)((float)tid * inv_gpr);                    // tid < 2^15: one correction step makes the quotient exact
-        row -= (row * gpr > tid) ? 1 : 0;
-        row += ((row + 1) * gpr <= tid) ? 1 : 0;
-        int col = tid - row * gpr;
-        const uint32_t skip = (uint32_t)(row_bytes - (size_t)gpr * 12);
-        for (int i0 = 0; i0 < total; i0 += 256 * CH) {
-            uint32_t d0[CH], d1[CH], d2[CH];
+        row -= (__mul24(row, gpr) > tid) ? 1 : 0;
+        row += (__mul24(row + 1, gpr) <= tid) ? 1 : 0;
+        int col = tid - __mul24(row, gpr);
+        const uint32_t skip = (uint32_t)(row_bytes - (size_t)gpr * 12);   // < 2^24 (the source is at most 4096 pixels wide)
+        const uint32_t off_last = (uint32_t)(sy_max - sy_min) * skip + (uint32_t)(total - 1) * 12u;
+        uint32_t d0[CH], d1[CH], d2[CH];
+        auto load_pass = [&](int i0) {
 #pragma unroll
             for (int c = 0; c < CH; c++) {
                 const int i = i0 + c * 256 + tid;
-                d0[c] = d1[c] = d2[c] = 0u;
-                if (i < total) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(src + ((uint32_t)row * skip + (uint32_t)i * 12u));
-#if defined(IRMV_FABL) && (IRMV_FABL & 1)
-                    d0[c] = (uint32_t)i; d1[c] = (uint32_t)row; d2[c] = (uint32_t)col; (void)q;
-#else
-                    d0[c] = q[0]; d1[c] = q[1]; d2[c] = q[2];
-#endif
-                }
+                // (unconditional, past the end the region's last group again: loads under a branch are waited for one by one)
+                const uint32_t off = i < total ? __umul24((uint32_t)row, skip) + __umul24((uint32_t)i, 12u) : off_last;
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(src + off);
+                d0[c] = q[0]; d1[c] = q[1]; d2[c] = q[2];
                 col += dr; row += dq;
                 if (col >= gpr) { col -= gpr; row++; }
             }
+        };
+        auto store_pass = [&](int i0) {
 #pragma unroll
             for (int c = 0; c < CH; c++) {
                 const int i = i0 + c * 256 + tid;
@@ -166,12 +156,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
                     *reinterpret_cast<uint4 *>(s_px + 4 * i) = o;
                 }
             }
+        };
+        // the first pass in straight-line code: at a loop header the compiler waits for (nearly) every load in flight --
+        // the weights -- before the pass's own loads are issued
+        load_pass(0);
+        store_pass(0);
+        for (int i0 = 256 * CH; i0 < total; i0 += 256 * CH) {
+            load_pass(i0);
+            store_pass(i0);
         }
     }
-    // taps relative to the region, one dword each: i0 | i1 << 10 | w << 20 (w <= 2048); all ones = outside / padding
+    // taps relative to the region, one dword each: i0 | i1 << 10 | w << 20 (w <= 2048); all ones = outside / padding.
+    // (The empty asm pins the first use of the loaded tap HERE: the compiler otherwise starts packing it right behind its
+    // load, and the wait that takes -- for every load issued so far -- lands in front of the source loads.)
+    asm volatile("" : "+v"(my_tap.i0), "+v"(my_tap.i1), "+v"(my_tap.w1));
     if (tid < INW + INH) {
         const int base = tap_x ? x0 : sy_min;
-        const uint32_t pk = my_tap.i0 < 0 ? 0xffffffffu : (uint32_t)(my_tap.i0 - base) | ((uint32_t)(my_tap.i1 - base) << 10) | ((uint32_t)my_tap.w1 << 20);
+        const uint32_t pk = (!tap_ok || my_tap.i0 < 0) ? 0xffffffffu : (uint32_t)(my_tap.i0 - base) | ((uint32_t)(my_tap.i1 - base) << 10) | ((uint32_t)my_tap.w1 << 20);
         if (tap_x) s_tx[tid] = pk; else s_ty[tid - INW] = pk;
     }
     if (tid < 48) s_bias[tid] = bias_v;
@@ -185,17 +186,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
         const float inv255 = 1.0f / 255.0f;   // (half)(q * inv255) == (half)(q / 255.0f) for every q in 0..255 (tests/test_oracle_preprocess.py)
         if (tid < INH) s_in[tid * INP + INW] = (half4){0, 0, 0, 0};   // the extra column of every row stays zero
         // 19 x 67 = 1273 pixels = five trips of 256 lanes (walking the padded 19 x 68 grid would need a sixth for 12 pixels)
-#if defined(IRMV_FABL) && (IRMV_FABL & 2)
-        if (a.fastx) {
-            for (int pp = tid; pp < INH * INW; pp += 256) {
-                const int ly = pp / INW, lx = pp - ly * INW;
-#if IRMV_FABL & 4096
-                if (a.net == 12345)
-#endif
-                s_in[ly * INP + lx] = (half4){padv, padv, padv, (half_t)0.0f};
-            }
-        } else
-#endif
         if (a.fastx) {
             // Columns at exactly 2 : 1 (every x tap = (2 k, 2 k + 1) with weight 1/2: 1280 -> 640): the horizontal blend
             // of a channel is 1024 (p0 + p1), so with s = p0 + p1 of the two tap rows the fixed-point result
@@ -298,13 +288,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const bool c0_inside = 2 * oy0 - 1 >= 0 && 2 * oy0 - 1 + C0H <= W0 && 2 * ox0 - 1 >= 0 && 2 * ox0 - 1 + C0W <= W0;   // no model.1 padding in this tile
         constexpr int KT = (NTILES + 3) / 4;   // tiles per wave (the last one may not exist for the upper waves)
-        constexpr int BT = IRMV_FRONT_BT;
+        constexpr int BT = 2;
 #pragma unroll
-#if defined(IRMV_FABL) && (IRMV_FABL & 4)
-        for (int k0 = 0; k0 < 0; k0 += BT) {
-#else
         for (int k0 = 0; k0 < KT; k0 += BT) {
-#endif
             half8 bf[BT][2];
             f32x4 acc[BT];
             int lyv[BT], lxv[BT];
@@ -323,31 +309,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
                     const int kh = s == 0 ? (g >> 1) : 2;          // k-step 1: kernel row 2 (g < 2) / no tap (row 2 again)
-#if defined(IRMV_FABL) && (IRMV_FABL & 2048)
-                    bf[k][s] = A00; bf[k][s][0] = (half_t)(float)(lyv[k] + kh); bf[k][s][1] = (half_t)(float)lxv[k];
-                    if (a.net == 12345) bf[k][s] = *reinterpret_cast<const half8 *>(s_in + tid);   // keeps stage A2 alive
-#else
                     bf[k][s] = *reinterpret_cast<const half8 *>(s_in + (2 * lyv[k] + kh) * INP + 2 * lxv[k] + 2 * (g & 1));
-#endif
                 }
             }
 #pragma unroll
             for (int k = 0; k < BT; k++) {
                 if (k0 + k >= KT) continue;
-#if defined(IRMV_FABL) && (IRMV_FABL & 512)
-                acc[k] = (f32x4){(float)bf[k][0][0], (float)bf[k][0][1], (float)bf[k][0][2], (float)bf[k][0][3]};
-#else
                 acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A00, bf[k][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#endif
             }
 #pragma unroll
             for (int k = 0; k < BT; k++) {
                 if (k0 + k >= KT) continue;
-#if defined(IRMV_FABL) && (IRMV_FABL & 512)
-                acc[k][0] += (float)bf[k][1][0]; acc[k][1] += (float)bf[k][1][1];
-#else
                 acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A01, bf[k][1], acc[k], 0, 0, 0);
-#endif
             }
 #pragma unroll
             for (int k = 0; k < BT; k++) {
@@ -360,11 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const float v = acc[k][i] + bias0[i];
-#if defined(IRMV_FABL) && (IRMV_FABL & 256)
-                            o[i] = (half_t)v;
-#else
                             o[i] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
-#endif
                         }
                     }
                     *reinterpret_cast<half4 *>(s_c0 + (size_t)((ly * 2 + (lx & 1)) * C0HALF + (lx >> 1)) * 16 + g * 4) = o;
@@ -372,9 +341,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
             }
         }
     }
-#if IRMV_FRONT_A1_LATE
-    IRMV_FRONT_LOAD_A1()   // (forty registers that stage B's batches need more: the loads ride under the barrier)
-#endif
     FSTAMP(6);
     __syncthreads();
     FSTAMP(7);
@@ -387,12 +353,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
-#if defined(IRMV_FABL) && (IRMV_FABL & 8)
-        for (int ks = 0; ks < 0; ks++) {
-#else
 #pragma unroll
         for (int ks = 0; ks < 5; ks++) {
-#endif
             const int tap = 2 * ks + (g >> 1);
             const int kh = tap / 3, kw = tap - kh * 3;
             half8 B[MTC];
@@ -426,16 +388,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_FRONT_
                     vals[i] = acc[mt][0][i] + bias1[i];
                     vals[4 + i] = acc[mt][1][i] + bias1[4 + i];
                 }
-#if !(defined(IRMV_FABL) && (IRMV_FABL & 8))
 #pragma unroll
                 for (int i = 0; i < 8; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
-#endif
                 half8 o;
 #pragma unroll
                 for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
-#if defined(IRMV_FABL) && (IRMV_FABL & 64)
-                if (o[0] == (half_t)12345.0f)
-#endif
                 *reinterpret_cast<half8 *>(a.out + ((size_t)(b * W1 + oy) * W1 + ox) * a.out_ld + g * 8) = o;
             }
         }
