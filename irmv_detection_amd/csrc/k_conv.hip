@@ -602,7 +602,7 @@ __device__ int g_stagger_sleeps = 0;
 #endif
 // The kernel's body as a device function of (workgroup index, grid size), so that one launch can serve several layers
 // (conv3x3_lds_multi below); conv3x3_lds_kernel itself is the thin wrapper behind it.
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0>
 __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch,
                                                  int wg_x, int wg_y, int grid_x, int grid_y)
 {
@@ -737,10 +737,15 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             if ((IRMV_ABL & 1) && (l_im | l_chunk)) break;
+            if (CM > 0 && l_im != 0) break;                // chunk-major: the chunk's weights are in LDS already
             const int e = tid + i * 256;
             if (e < 9 * NT * 64) w[i] = wsrc[(size_t)l_chunk * (9 * NT * 64) + e];
         }
-        if (++l_chunk == chunks) { l_chunk = 0; l_im++; }
+        if constexpr (CM > 0) {
+            if (++l_im == nimg) { l_im = 0; l_chunk++; }
+        } else {
+            if (++l_chunk == chunks) { l_chunk = 0; l_im++; }
+        }
     };
     auto write_lds = [&](const half8 (&p)[PMAX], const half8 (&w)[WPT]) {
 #pragma unroll
@@ -751,20 +756,28 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
             if ((IRMV_ABL & 1) && (c_im | c_chunk)) break;
+            if (CM > 0 && c_im != 0) break;
             const int e = tid + i * 256;
             if (e < 9 * NT * 64) s_w[e] = w[i];
         }
     };
 
-    f32x4 acc[MT][NT];
+    // CM > 0 (chunk-major): the workgroup's CM images each keep their own accumulators, so that a chunk's weights are
+    // staged ONCE and every image's patch of that chunk runs against them (image-major order re-stages the 9 NT KiB of
+    // weights per (image, chunk) step: for the small tiles that is more LDS traffic than the patch itself)
+    constexpr int NA = CM > 0 ? CM : 1;
+    f32x4 acc[NA][MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+    for (int ai = 0; ai < NA; ai++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[ai][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // epilogue of one image (bias, SiLU, shortcut, fp16, NHWC store); clears the accumulators for the next one
     const int nt0 = nblk * NT;
-    auto store_tile = [&](int im) {
+    auto store_tile = [&](int im, auto ai_) {
+        auto &accx = acc[decltype(ai_)::value];
         // A fragments of the fused 1x1: loaded by EVERY lane (an MFMA reads its A rows from all 64 lanes, whatever the
         // pixel mask of the B side says), live only for the epilogue
         half8 W2[N2 > 0 ? N2 : 1][2];
@@ -816,8 +829,8 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
                         float vals[8];
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            vals[i] = acc[mt][2 * u][i] + bs[u][i];
-                            vals[4 + i] = acc[mt][2 * u + 1][i] + bs[u][4 + i];
+                            vals[i] = accx[mt][2 * u][i] + bs[u][i];
+                            vals[4 + i] = accx[mt][2 * u + 1][i] + bs[u][4 + i];
                         }
 #pragma unroll
                         for (int i = 0; i < 8; i++) if (!(IRMV_ABL & 8)) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
@@ -872,7 +885,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
                     float vals[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        vals[i] = acc[mt][0][i] + bs[0][i];
+                        vals[i] = accx[mt][0][i] + bs[0][i];
                         vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
                     }
                     if (a.res) {
@@ -884,17 +897,19 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; nt++) accx[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
 
+    using I0 = std::integral_constant<int, 0>;
     const int steps = nimg * chunks;
     // The staging loads of the NEXT step ride inside this step's tap loop, a few per tap (SPREAD): issued in one burst
     // after the barrier they fill the CU's vector-memory queue (17 wave-instructions of 1 KiB against 64 B/clk) and the
     // wave sits in the issue stall instead of starting its MFMAs.  The last step re-loads its own pieces (no branch).
     constexpr int NPIECE = PMAX + WPT, PER_TAP = (NPIECE + 8) / 9;
-    auto taps = [&](auto spread) {
+    auto taps = [&](auto spread, auto ai_) {
         constexpr bool SPREAD = decltype(spread)::value;
+        auto &accx = acc[decltype(ai_)::value];
         size_t off = 0;
         if constexpr (SPREAD) {
             if (l_im == nimg) { l_im = nimg - 1; l_chunk = chunks - 1; }
@@ -926,7 +941,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
-                    if (!(IRMV_ABL & 4)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[nt], B[mt], acc[mt][nt], 0, 0, 0);
+                    if (!(IRMV_ABL & 4)) accx[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[nt], B[mt], accx[mt][nt], 0, 0, 0);
             if constexpr (SPREAD) __builtin_amdgcn_sched_barrier(0x38f);   // everything but vector-memory instructions may cross
         }
         if constexpr (SPREAD) {
@@ -934,10 +949,10 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         }
     };
     auto mma_step = [&]() {
-        taps(std::false_type{});
+        taps(std::false_type{}, I0{});
         __syncthreads();
         if (++c_chunk == chunks) {
-            store_tile(img + c_im);
+            store_tile(img + c_im, I0{});
             c_chunk = 0;
             c_im++;
         }
@@ -962,13 +977,13 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         for (int s = 0; s < steps; s++) {
             write_lds(rp[0], rw[0]);
             __syncthreads();
-            if (pend_im >= 0) { store_tile(pend_im); pend_im = -1; }
+            if (pend_im >= 0) { store_tile(pend_im, I0{}); pend_im = -1; }
             if (s + 1 < steps) issue_loads(rp[0], rw[0]);
-            taps(std::false_type{});
+            taps(std::false_type{}, I0{});
             __syncthreads();
             if (++c_chunk == chunks) { pend_im = img + c_im; c_chunk = 0; c_im++; }
         }
-        if (pend_im >= 0) store_tile(pend_im);
+        if (pend_im >= 0) store_tile(pend_im, I0{});
         return;
     }
 #endif
@@ -988,15 +1003,15 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
 #if IRMV_EXP & 8
             if (s + 1 < steps) issue_loads(rp[0], rw[0]);
             stamp(3);
-            taps(std::false_type{});
+            taps(std::false_type{}, I0{});
 #else
             stamp(3);
-            taps(std::true_type{});
+            taps(std::true_type{}, I0{});
 #endif
             stamp(4);
             __syncthreads();
             stamp(5);
-            if (++c_chunk == chunks) { store_tile(img + c_im); c_chunk = 0; c_im++; stamp(6); }
+            if (++c_chunk == chunks) { store_tile(img + c_im, I0{}); c_chunk = 0; c_im++; stamp(6); }
         }
         if (tid == 0) {
             for (int k = 0; k < 7; k++) atomicAdd(&g_phase[k], (unsigned long long)t_acc[k]);
@@ -1007,20 +1022,45 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         return;
     }
 #endif
-    if constexpr (!PF2) {
+    if constexpr (CM > 0) {
+        static_assert(!PF2 && CM <= 4, "chunk-major order: one step of staging lead, at most four images");
+        auto each_image = [&](auto f) {
+            f(std::integral_constant<int, 0>{});
+            if constexpr (CM > 1) f(std::integral_constant<int, 1>{});
+            if constexpr (CM > 2) f(std::integral_constant<int, 2>{});
+            if constexpr (CM > 3) f(std::integral_constant<int, 3>{});
+        };
+        issue_loads(rp[0], rw[0]);
+        for (int c = 0; c < chunks; c++) {
+            each_image([&](auto ai) {
+                constexpr int AI = decltype(ai)::value;
+                if (AI < nimg) {                                 // workgroup-uniform (the batch's last group may be short)
+                    write_lds(rp[0], rw[0]);                     // (c_im == AI: the weights go with image 0)
+                    __syncthreads();
+                    if (!(c == chunks - 1 && AI == nimg - 1)) issue_loads(rp[0], rw[0]);
+                    taps(std::false_type{}, ai);
+                    __syncthreads();
+                    if (++c_im == nimg) { c_im = 0; c_chunk++; }
+                }
+            });
+        }
+        each_image([&](auto ai) {
+            if (decltype(ai)::value < nimg) store_tile(img + decltype(ai)::value, ai);
+        });
+    } else if constexpr (!PF2) {
         issue_loads(rp[0], rw[0]);
         for (int s = 0; s < steps; s++) {
             write_lds(rp[0], rw[0]);
             __syncthreads();
             if constexpr (MT == 4 && !(IRMV_EXP & 8)) {
-                taps(std::true_type{});                          // next step's loads spread over the taps
+                taps(std::true_type{}, I0{});                          // next step's loads spread over the taps
             } else {   // small tiles: the burst is short and the spread costs more than it saves (measured)
                 if (s + 1 < steps) issue_loads(rp[0], rw[0]);
-                taps(std::false_type{});
+                taps(std::false_type{}, I0{});
             }
             __syncthreads();
             if (++c_chunk == chunks) {
-                store_tile(img + c_im);
+                store_tile(img + c_im, I0{});
                 c_chunk = 0;
                 c_im++;
             }
@@ -1043,10 +1083,10 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     }
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
 {
-    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2, CM>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // Several independent 3x3 layers in ONE launch (the Detect branches of the three levels in a single-frame step: fifteen
@@ -1113,23 +1153,38 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
     return g.bytes;
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0>
 static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int ipw, const LdsGeom &g, hipStream_t s)
 {
     static unsigned long long attr_done = 0;   // per instantiation: devices whose dynamic-LDS limit has been raised
     once_per_device(attr_done, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int groups = (batch + ipw - 1) / ipw;
-    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
                        wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch);
 }
 
-bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2)
+bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2, int cm)
 {
     const LdsGeom g = lds_geom(a, stride, mt, nt);
     if (!g.bytes) return false;
     if (ipw < 1) ipw = 1;
+    if (cm) {   // chunk-major order over the workgroup's cm = ipw images (16 cm mt nt accumulator registers)
+        if (cm != ipw || pf2) return false;
+        if (a.n2 > 0 && (stride != 1 || nt != 4 || a.cout_pad != 64 || !a.pair || a.res)) return false;
+#define IRMV_LDS_CM(ST_, MT_, NT_, CM_, N2_)                                                               \
+        if (stride == ST_ && mt == MT_ && nt == NT_ && cm == CM_ && a.n2 == N2_) {                         \
+            if (g.tile2d) launch_lds_inst<ST_, MT_, NT_, true, N2_, false, CM_>(a, wl, batch, ipw, g, s);  \
+            else launch_lds_inst<ST_, MT_, NT_, false, N2_, false, CM_>(a, wl, batch, ipw, g, s);          \
+            return true;                                                                                   \
+        }
+        IRMV_LDS_CM(1, 1, 4, 4, 0) IRMV_LDS_CM(1, 1, 4, 2, 0) IRMV_LDS_CM(1, 2, 4, 2, 0)
+        IRMV_LDS_CM(2, 1, 4, 4, 0) IRMV_LDS_CM(2, 1, 4, 2, 0) IRMV_LDS_CM(2, 2, 4, 2, 0)
+        IRMV_LDS_CM(1, 1, 4, 4, 1) IRMV_LDS_CM(1, 2, 4, 2, 1) IRMV_LDS_CM(1, 1, 4, 4, 4) IRMV_LDS_CM(1, 2, 4, 2, 4)
+#undef IRMV_LDS_CM
+        return false;
+    }
     if (pf2) {   // two-steps-ahead staging: the small pixel tiles (MT = 1), plain epilogue
         if (mt != 1 || a.n2 > 0) return false;
 #define IRMV_LDS_P(ST_, NT_)                                                                     \
