@@ -1311,7 +1311,8 @@ static int autotune_convs(irmv_engine *e)
                     if (ok && h.deep) ok = (h.mt == 1 || (h.mt == 2 && h.nt == 1)) && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1;
                     if (ok && h.ct) ok = op.w_lds[0] != nullptr;
                     if (ok && h.pf2) ok = h.lds && h.mt == 1 && !want_fuse;
-                    if (ok && h.cm) ok = h.lds && !h.pf2 && h.cm == h.ipw && h.nt == 4 && ((h.mt == 1 && (!want_fuse || h.cm == 4)) || (h.mt == 2 && h.cm == 2));
+                    if (ok && h.cm) ok = !getenv("IRMV_NO_CM") && h.lds && !h.pf2 && h.cm == h.ipw && h.nt == 4 && ((h.mt == 1 && (!want_fuse || h.cm == 4)) || (h.mt == 2 && h.cm == 2));
+                    if (ok && !h.cm && getenv("IRMV_FORCE_CM") && lds_ok && counts[pass] >= 2) ok = false;   // parity tests: the chunk-major tiles wherever one exists
                     if (ok) {
                         best_cfg = op.cfg;
                         best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct; best_cfg.pw = h.pw; best_cfg.pf2 = h.pf2; best_cfg.cm = h.cm;
@@ -1378,6 +1379,7 @@ static int autotune_convs(irmv_engine *e)
                             ConvCfg c = op.cfg;
                             c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = ipw;
                             TRY(time_cfg(c));
+                            if (getenv("IRMV_FORCE_CM") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                         }
                 // 1x1 layers: the persistent pointwise kernel (same operands, same k order as the direct kernel)
                 if (conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW")) {
