@@ -277,7 +277,7 @@ irmv_engine::~irmv_engine()
         std::vector<long long> h((size_t)cfg.num_slots * 8);
         if (hipMemcpy(h.data(), dbg_dev, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             for (int s = 0; s < cfg.num_slots && s < 4; s++)
-                fprintf(stderr, "[nms stamps] slot %d: sort %lld masks %lld walk %lld out+pnp %lld cycles; n=%lld kept=%lld\n", s, h[s * 8 + 1] - h[s * 8 + 0],
+                fprintf(stderr, "[nms stamps] slot %d: keys+decode %lld sort %lld masks %lld walk %lld out+pnp %lld cycles; n=%lld kept=%lld\n", s, h[s * 8 + 7] - h[s * 8 + 0], h[s * 8 + 1] - h[s * 8 + 7],
                         h[s * 8 + 2] - h[s * 8 + 1], h[s * 8 + 3] - h[s * 8 + 2], h[s * 8 + 4] - h[s * 8 + 3], h[s * 8 + 5], h[s * 8 + 6]);
     }
     for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);

@@ -376,41 +376,59 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     __syncthreads();
     if (a.counts) {
         // ---- 0'. scan_decode_kernel has filled the frame's key list and decoded the candidate anchors' boxes ----
+        // (a lane's first key is requested together with the count, not behind it: one memory round trip instead of two
+        // for frames of up to 1024 candidates; beyond the count it is whatever the list holds, and is not used)
+        const unsigned long long k_first = gk[tid < a.key_cap ? tid : 0];
         int n = a.counts[b];
         n = n < 0 ? 0 : (n > a.key_cap ? a.key_cap : n);           // whatever the counter holds, reads stay inside the list
-        if (n <= kCandCap)
-            for (int i = tid; i < n; i += blockDim.x) skeys[i] = gk[i];
+        if (n <= kCandCap) {
+            if (tid < n) skeys[tid] = k_first;
+            for (int i = tid + blockDim.x; i < n; i += blockDim.x) skeys[i] = gk[i];
+        }
         __syncthreads();                                           // every lane has read the count
         if (tid == 0) { s_ncand = n; a.counts[b] = 0; }            // the next step of this slot starts from zero
         if (a.keys_only) {
             // keys from the class-branch conv epilogues: the candidates' boxes are decoded here, four lanes per candidate (an
             // anchor with several classes above threshold is decoded once per class: same value, same address)
             const int q = tid & 3, base = lane & ~3;
-            for (int i0 = 0; i0 < n; i0 += 256) {
-                const int ci = i0 + (tid >> 2);
-                const bool live = ci < n;                          // quad-uniform
-                const unsigned long long key = live ? (n <= kCandCap ? skeys[ci] : gk[ci]) : 0ull;
-                const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
-                const int an = live ? anchor_of(id, a.nc, a.A) : 0;
-                int ix, iy, st, lbase, lhw, rin;
-                anchor_geom(an, a.net, ix, iy, st, lbase, lhw, rin);
-                const float *rec = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
-                float l[16];
+            // two rounds of 256 candidates per trip, both rounds' DFL logits requested before either is used (a store to the
+            // box list between them would otherwise order the second round's loads behind the first round's arithmetic)
+            for (int i0 = 0; i0 < n; i0 += 512) {
+                f32x4 v[2][4];
+                int an_[2];
+                bool live_[2];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const f32x4 v = reinterpret_cast<const f32x4 *>(rec + 16 * q)[i];
-                    l[4 * i] = v[0]; l[4 * i + 1] = v[1]; l[4 * i + 2] = v[2]; l[4 * i + 3] = v[3];
+                for (int u = 0; u < 2; u++) {
+                    const int ci = i0 + u * 256 + (tid >> 2);
+                    live_[u] = ci < n;                             // quad-uniform
+                    const unsigned long long key = live_[u] ? (n <= kCandCap ? skeys[ci] : gk[ci]) : 0ull;
+                    const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
+                    an_[u] = live_[u] ? anchor_of(id, a.nc, a.A) : 0;
+                    int ix, iy, st, lbase, lhw, rin;
+                    anchor_geom(an_[u], a.net, ix, iy, st, lbase, lhw, rin);
+                    const float *rec = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[u][i] = reinterpret_cast<const f32x4 *>(rec + 16 * q)[i];
                 }
-                const float d = dfl_side(l);
-                const float dl = __shfl(d, base), dt = __shfl(d, base + 1), dr = __shfl(d, base + 2), db = __shfl(d, base + 3);
-                if (live && q == 0) {
-                    const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)st;
-                    f32x4 box;
-                    box[0] = (ax - dl) * sf;
-                    box[1] = (ay - dt) * sf;
-                    box[2] = (ax + dr) * sf;
-                    box[3] = (ay + db) * sf;
-                    reinterpret_cast<f32x4 *>(a.boxes)[(size_t)b * a.A + an] = box;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (i0 + u * 256 >= n) break;                  // workgroup-uniform
+                    float l[16];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { l[4 * i] = v[u][i][0]; l[4 * i + 1] = v[u][i][1]; l[4 * i + 2] = v[u][i][2]; l[4 * i + 3] = v[u][i][3]; }
+                    const float d = dfl_side(l);
+                    const float dl = __shfl(d, base), dt = __shfl(d, base + 1), dr = __shfl(d, base + 2), db = __shfl(d, base + 3);
+                    if (live_[u] && q == 0) {
+                        int ix, iy, st, lbase, lhw, rin;
+                        anchor_geom(an_[u], a.net, ix, iy, st, lbase, lhw, rin);
+                        const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)st;
+                        f32x4 box;
+                        box[0] = (ax - dl) * sf;
+                        box[1] = (ay - dt) * sf;
+                        box[2] = (ax + dr) * sf;
+                        box[3] = (ay + db) * sf;
+                        reinterpret_cast<f32x4 *>(a.boxes)[(size_t)b * a.A + an_[u]] = box;
+                    }
                 }
             }
         }
@@ -447,6 +465,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     decode_boxes(a, b, alist, alist ? s_nanch : a.A);   // boxes of the candidate anchors, in parallel over the whole workgroup
     }
     __syncthreads();   // keys in LDS / global and boxes in global are visible to the whole workgroup from here
+    IRMV_STAMP(7);
     const int n_total = s_ncand;
     int n_stored = n_total;
     bool preloaded = n_total <= kCandCap;   // then skeys already holds every key
@@ -497,23 +516,37 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         if (!preloaded)   // after a radix select skeys already holds the selected keys: gk[0..n_stored) would be the wrong ones
             for (int i = tid; i < n_stored; i += blockDim.x) skeys[i] = gk[i];
         __syncthreads();
-        // keys are unique, so "number of keys greater than mine" is a permutation
+        // keys are unique, so "number of keys greater than mine" is a permutation.  A key's count is split over P lanes (all
+        // 1024 of the workgroup for n >= 342: with one lane per key a 380-candidate frame kept six waves busy for 16 k cycles),
+        // each counting over its own stretch of the list; the partial counts meet in an LDS counter per key (the masks'
+        // buffer: free until phase 2).
         const int n8 = (n_stored + 7) & ~7;
+        int *s_rankacc = reinterpret_cast<int *>(ssup);
         for (int i = n_stored + tid; i < n8; i += blockDim.x) skeys[i] = 0ull;   // pad: never greater than a real key
+        for (int i = tid; i < n_stored; i += blockDim.x) s_rankacc[i] = 0;
         __syncthreads();
-        for (int i = tid; i < n_stored; i += blockDim.x) {
-            const unsigned long long mine = skeys[i];
-            int rank = 0;
-            for (int j = 0; j < n8; j += 8) {
-                const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(&skeys[j]);
-                const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 2]);
-                const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 4]);
-                const ulonglong2 k3 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 6]);
-                rank += (k0.x > mine) + (k0.y > mine) + (k1.x > mine) + (k1.y > mine) + (k2.x > mine) + (k2.y > mine) +
-                        (k3.x > mine) + (k3.y > mine);
+        if (n_stored > 0) {
+            const int P = min(16, (int)blockDim.x / n_stored);                  // lanes per key (n_stored <= 512: at least two)
+            const int per = ((n8 / 8 + P - 1) / P) * 8;                         // keys per stretch (a multiple of 8)
+            const int p = tid / n_stored, i = tid - p * n_stored;
+            const int j_lo = p * per, j_hi = min(j_lo + per, n8);
+            if (p < P && j_lo < j_hi) {
+                const unsigned long long mine = skeys[i];
+                int rank = 0;
+#pragma unroll 2
+                for (int j = j_lo; j < j_hi; j += 8) {
+                    const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(&skeys[j]);
+                    const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 2]);
+                    const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 4]);
+                    const ulonglong2 k3 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 6]);
+                    rank += (k0.x > mine) + (k0.y > mine) + (k1.x > mine) + (k1.y > mine) + (k2.x > mine) + (k2.y > mine) +
+                            (k3.x > mine) + (k3.y > mine);
+                }
+                if (P == 1) s_rankacc[i] = rank; else atomicAdd(&s_rankacc[i], rank);
             }
-            srank[rank] = mine;
         }
+        __syncthreads();
+        for (int i = tid; i < n_stored; i += blockDim.x) srank[s_rankacc[i]] = skeys[i];
         __syncthreads();
         sorted = srank;
     } else {
@@ -544,12 +577,12 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
 
     constexpr int kMatN = 512, kMatW = kMatN / 64;   // up to this many candidates the FULL suppression matrix fits ssup
     if (n <= kMatN) {
-        // ---- 2'. full matrix: M[i][w] bit jj <=> candidate j = 64 w + jj (j < i) has my class and IoU(j, i) > thr ----
+        // ---- 2'. full suppression matrix ----
         // Every IoU test the greedy walk can need, evaluated up front by the whole workgroup; the walk itself is then
-        // AND / ballot work on 64-bit words (no boxes, no per-class kept lists).  Same comparisons as the oracle's walk.
+        // AND / readlane work on 64-bit words (no boxes, no per-class kept lists).  Same comparisons as the oracle's walk.
         f32x4 *cbox = &stage_box[0][0];      // [1024] -> candidate boxes / classes in sorted order
         int *ccls = &stage_cls[0][0];
-        __shared__ unsigned long long s_keptw[kMatW];
+        __shared__ unsigned long long s_keptw[kMatW];   // per 64-candidate block: its survivors
         for (int i = tid; i < ((n + 63) & ~63); i += blockDim.x) {
             if (i < n) {
                 const uint32_t id = 0xffffffffu - (uint32_t)(sorted[i] & 0xffffffffu);
@@ -573,49 +606,60 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             }
         }
         __syncthreads();
-        for (int item = tid; item < n * nw; item += blockDim.x) {
-            const int w = item / n, i = item - w * n;          // consecutive lanes: consecutive i, same word -> broadcast reads of j
-            unsigned long long mask = 0ull;
-            const int j0 = w << 6;
-            if (j0 < i) {
-                const f32x4 bi = cbox[i];
-                const int ci = ccls[i];
-                const int jend = i - j0 < 64 ? i - j0 : 64;
-                // class filter first (the per-class word built above), then the IoU test only for the few same-class candidates
-                unsigned long long same = s_clsmask[ci][w];
-                if (jend < 64) same &= (1ull << jend) - 1ull;
-                while (same) {
-                    const int jj = __ffsll((long long)same) - 1;
-                    same &= same - 1ull;
-                    if (iou_gt(cbox[j0 + jj], bi, a.iou_thr)) mask |= 1ull << jj;
+        // Row i of the matrix: bit jj of word w <=> candidate j = 64 w + jj (j < i) has i's class and IoU(j, i) > thr -- who
+        // suppresses i if kept.  Rows are built for a range of 64-candidate blocks at a time (see below).
+        // (an item is HALF a word: twice the items of half the length spread more evenly over the 1024 lanes -- a row's cost
+        // is its same-class candidates in the word, anything from none to 64)
+        uint32_t *ssup32 = reinterpret_cast<uint32_t *>(ssup);
+        auto build_rows = [&](int b_lo, int b_hi) {            // rows of blocks [b_lo, b_hi): words 0 .. b_hi - 1
+            const int i_lo = b_lo << 6, rows = min(n, b_hi << 6) - i_lo;
+            for (int item = tid; item < 2 * rows * b_hi; item += blockDim.x) {
+                const int h = item & 1, it2 = item >> 1;
+                const int w = it2 / rows, i = i_lo + (it2 - w * rows);   // (nearly) consecutive lanes: consecutive i, same word -> broadcast reads of j
+                uint32_t mask = 0u;
+                const int j0 = (w << 6) + (h << 5);
+                if (j0 < i) {
+                    const f32x4 bi = cbox[i];
+                    const int ci = ccls[i];
+                    const int jend = i - j0 < 32 ? i - j0 : 32;
+                    // class filter first (the per-class word built above), then the IoU test only for the few same-class candidates
+                    uint32_t same = (uint32_t)(s_clsmask[ci][w] >> (h << 5));
+                    if (jend < 32) same &= (1u << jend) - 1u;
+                    while (same) {
+                        const int jj = __ffs((int)same) - 1;
+                        same &= same - 1u;
+                        if (iou_gt(cbox[j0 + jj], bi, a.iou_thr)) mask |= 1u << jj;
+                    }
                 }
+                ssup32[(i * kMatW + w) * 2 + h] = mask;
             }
-            ssup[i * kMatW + w] = mask;
-        }
-        __syncthreads();
-        IRMV_STAMP(2);
+        };
         // ---- 3'. greedy walk on wave 0, 64 candidates per step ----
-        if (wave == 0) {
-            int kept = 0;
-            for (int start = 0; start < n && kept < a.max_det; start += 64) {
-                const int blk = start >> 6, idx = start + lane;
+        auto walk_blocks = [&](int b_lo, int b_hi, int kept) -> int {
+            for (int blk = b_lo; blk < b_hi && kept < a.max_det; blk++) {
+                const int idx = (blk << 6) + lane;
                 const bool valid = idx < n;
                 bool alive = valid;
                 for (int w = 0; w < blk; w++)                      // suppressed by a kept candidate of an earlier block?
                     if (valid && (ssup[idx * kMatW + w] & s_keptw[w]) != 0ull) alive = false;
                 const unsigned long long sup = valid ? ssup[idx * kMatW + blk] : 0ull;
-                unsigned long long A = __ballot(alive);
-                int taken = 0;
-                for (unsigned long long todo = A; todo;) {          // walk the still-alive candidates in order
-                    const int j = __ffsll((long long)todo) - 1;
-                    if (kept + taken >= a.max_det) {
-                        A &= (1ull << j) - 1ull;                      // cap reached: drop j and everything after
-                        break;
-                    }
-                    taken++;
-                    const unsigned long long col = __ballot((sup >> j) & 1ull);   // lanes that j suppresses (all > j)
-                    A &= ~col;
-                    todo = A & ~((2ull << j) - 1ull);
+                // The block's in-order resolve, without walking it candidate by candidate (one wave alone on its SIMD pays
+                // every instruction's full latency: ~200 cycles per survivor that way).  A candidate whose possible
+                // suppressors (its sup bits) are all DECIDED is decided itself: kept iff none of them was kept.  Every round
+                // decides at least the first undecided candidate, usually most of them; the kept set is the sequential walk's.
+                unsigned long long U = __ballot(alive), K = 0ull;   // undecided, kept
+                while (U) {
+                    const bool ready = ((U >> lane) & 1ull) && (sup & U) == 0ull;
+                    const unsigned long long R = __ballot(ready);
+                    K |= __ballot(ready && (sup & K) == 0ull);
+                    U &= ~R;
+                }
+                // the cap: the walk stops with the max_det-th survivor (a candidate's fate depends on the ones before it only)
+                const int room = a.max_det - kept;
+                unsigned long long A = K;
+                if (__popcll(K) > room) {
+                    const bool over = ((K >> lane) & 1ull) && __popcll(K & ((1ull << lane) - 1ull)) >= room;
+                    A = K & ~__ballot(over);
                 }
                 const bool mine = (A >> lane) & 1ull;
                 const int pos = kept + __popcll(A & ((1ull << lane) - 1ull));
@@ -628,6 +672,16 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
                 wave_lds_sync();
                 kept += __popcll(A);
             }
+            return kept;
+        };
+        // (Measured and dropped: rows in two stages, the second only if the walk over the first has not filled max_det -- on
+        // the 380-candidate benchmark frame the hundredth survivor sits in the fifth of six blocks, and the extra barriers cost
+        // more than the unbuilt rows save.)
+        build_rows(0, nw);
+        __syncthreads();
+        IRMV_STAMP(2);
+        if (wave == 0) {
+            const int kept = walk_blocks(0, nw, 0);
             if (lane == 0) s_kept = kept;
         }
     } else {
