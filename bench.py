@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames-per-step", type=int, default=128)
+    ap.add_argument("--frames-per-step", type=int, default=192)
     ap.add_argument("--src", default="1280x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96)
@@ -307,7 +307,7 @@ def main():
         traffic = None
         import re
         base_name = re.sub(r"_i\d+", "", dom_name)
-        default_cfg = (args.model, args.net, args.int8, B) == ("yolov8n", 640, False, 128)   # what the counter files were collected on
+        default_cfg = (args.model, args.net, args.int8) == ("yolov8n", 640, False) and per_graph == 64   # what the counter files were collected on: 64-frame graphs
         for tname in (("r02_traffic.json", "r01_traffic.json") if default_cfg else ()):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):

@@ -72,11 +72,12 @@ typedef struct irmv_engine_cfg {
     const void *weights_blob;  /* .irmw image in host memory, or in device memory if weights_on_device */
     uint64_t weights_bytes;
     int32_t weights_on_device; /* 1: weights_blob is a device pointer (e.g. filled by an RCCL broadcast) */
-    int32_t num_streams;       /* compute streams (0 = default: 2, or one per slot for engines of <= 4 slots).  A multi-slot
-                                  submit() is cut into that many sub-batches replayed as concurrent graphs, whose launch gaps and
-                                  tails fill each other (measured at 128 frames/step: 2 streams +9 % over 1; 3 and 4 streams
-                                  -10 %); a single-slot submit rides stream (slot mod num_streams), so the steps of different
-                                  slots overlap (three single frames in flight: 4.7 k FPS against 2.0 k one at a time) */
+    int32_t num_streams;       /* compute streams (0 = default: one per 64 slots, at least 2 and at most 4; one per slot for engines
+                                  of <= 4 slots).  A multi-slot submit() is cut into that many sub-batches replayed as concurrent
+                                  graphs, whose launch gaps and tails fill each other (measured: 128 frames as 2 x 64 +9 % over 1 x 128,
+                                  as 3 or 4 graphs -10 %; 192 frames as 3 x 64 +5 % over 128 as 2 x 64); a single-slot submit rides
+                                  stream (slot mod num_streams), so the steps of different slots overlap (three single frames in
+                                  flight: 6.1 k FPS against 2.7 k one at a time) */
     /* Source of the four armor points PnP consumes.  The reference obtains them by classical CV inside
      * each bbox (IrmDetector::extract_armors, src/irm_detector.cpp:292-355); a pose-style model carries them
      * in a keypoint head.  IRMV_POINTS_AUTO picks the keypoint head when the model has one. */

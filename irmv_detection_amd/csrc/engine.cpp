@@ -673,9 +673,9 @@ static int build_engine(irmv_engine *e)
         HIP_TRY(hipEventCreateWithFlags(&e->ev_level[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
     }
-    // default: two concurrently replayed sub-batches for batched engines (measured best); a stream per slot
+    // default: batched engines replay concurrent sub-batches of ~64 frames, two to four of them; a stream per slot
     // for engines of TripleBuffer size, whose single-slot steps then overlap
-    e->num_streams = c.num_streams > 0 ? c.num_streams : (c.num_slots <= 4 ? c.num_slots : 2);
+    e->num_streams = c.num_streams > 0 ? c.num_streams : (c.num_slots <= 4 ? c.num_slots : std::min(4, std::max(2, (c.num_slots + 63) / 64)));   // batched: graphs of ~64 frames
     if (const char *ns = getenv("IRMV_STREAMS")) e->num_streams = atoi(ns);
     e->num_streams = std::max(1, std::min({e->num_streams, 8, c.num_slots}));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));

@@ -1,5 +1,5 @@
 """End-to-end refinement of the autotuner's table: the per-layer autotuner times every conv ALONE, but the benchmarked step
-replays two 64-frame graphs concurrently, where a tile's footprint (LDS, registers, workgroups) also decides how well it
+replays several 64-frame graphs concurrently, where a tile's footprint (LDS, registers, workgroups) also decides how well it
 shares the chip with the other graph's kernels -- a tile that is 5 % slower alone can be 2 % faster in the step.
 Coordinate descent over the heavy batched (n64) entries of a table, the objective being bench.py's own FPS; every tile it
 may pick is one the engine offers for that layer and all of them are bitwise neutral (the engine re-tunes an entry it does
