@@ -1200,7 +1200,7 @@ static void tune_cache_load()
     int mt, nt, lds, ipw;
     while (f >> key >> mt >> nt >> lds >> ipw) {
         ConvCfg c{};
-        c.mt = mt; c.nt = nt; c.lds = (lds & 1) != 0; c.deep = (lds & 2) != 0; c.ct = (lds & 4) != 0; c.pw = (lds & 8) != 0; c.pf2 = (lds & 16) != 0; c.cm = (lds & 64) ? 2 : ((lds & 128) ? 4 : 0); c.ipw = ipw;   // bit 0 LDS family, 1 deep prefetch, 2 direct kernel in the LDS family's K order, 3 pointwise kernel, 4 two-step staging, 6 / 7 LDS family chunk-major over 2 / 4 images
+        c.mt = mt; c.nt = nt; c.lds = (lds & 1) != 0; c.deep = (lds & 2) != 0; c.ct = (lds & 4) != 0; c.pw = (lds & 8) != 0; c.pf2 = (lds & 16) != 0; c.cm = (lds & 64) ? 2 : ((lds & 128) ? 4 : 0); c.w8 = (lds & 256) != 0; c.ipw = ipw;   // bit 0 LDS family, 1 deep prefetch, 2 direct kernel in the LDS family's K order, 3 pointwise kernel, 4 two-step staging, 6 / 7 LDS family chunk-major over 2 / 4 images, 8 LDS family 8-wave workgroup
         g_tune_cache[key] = c;
     }
 }
@@ -1212,14 +1212,14 @@ static void tune_cache_save()
     std::lock_guard<std::mutex> lk(g_tune_mu);
     std::ofstream f(path);
     for (auto &kv : g_tune_cache)
-        f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0) | (kv.second.pw ? 8 : 0) | (kv.second.pf2 ? 16 : 0) | (kv.second.cm == 2 ? 64 : 0) | (kv.second.cm == 4 ? 128 : 0)) << ' ' << kv.second.ipw << '\n';
+        f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0) | (kv.second.pw ? 8 : 0) | (kv.second.pf2 ? 16 : 0) | (kv.second.cm == 2 ? 64 : 0) | (kv.second.cm == 4 ? 128 : 0) | (kv.second.w8 ? 256 : 0)) << ' ' << kv.second.ipw << '\n';
 }
 
 static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int count, hipStream_t s)
 {
     const int li = c.nt == 4 ? 2 : (c.nt == 2 ? 1 : 0);
     if (c.pw) return launch_conv_pw(c, a, s);
-    if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s, c.pf2, c.cm);
+    if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s, c.pf2, c.cm, c.w8);
     if (c.ct) {   // direct kernel in the LDS family's K order, on that family's nt = 1 weight packing
         if (!op.w_lds[0] || a.n2 > 0) return false;
         ConvArgs a2 = a;
@@ -1232,8 +1232,8 @@ static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int coun
 static void cfg_name(const ConvCfg &c, char *buf, int n)
 {
     if (c.pw) snprintf(buf, n, "conv1x1s1_pw");
-    else if (c.lds && c.ipw > 1) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d_i%d%s", c.stride, c.mt, c.nt, c.ipw, c.cm ? "_cm" : (c.pf2 ? "_p2" : ""));
-    else if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d%s", c.stride, c.mt, c.nt, c.pf2 ? "_p2" : "");
+    else if (c.lds && c.ipw > 1) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d_i%d%s%s", c.stride, c.mt, c.nt, c.ipw, c.cm ? "_cm" : (c.pf2 ? "_p2" : ""), c.w8 ? "_w8" : "");
+    else if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d%s%s", c.stride, c.mt, c.nt, c.pf2 ? "_p2" : "", c.w8 ? "_w8" : "");
     else conv_cfg_name(c, buf, n);
 }
 
@@ -1312,10 +1312,13 @@ static int autotune_convs(irmv_engine *e)
                     if (ok && h.ct) ok = op.w_lds[0] != nullptr;
                     if (ok && h.pf2) ok = h.lds && h.mt == 1 && !want_fuse;
                     if (ok && h.cm) ok = !getenv("IRMV_NO_CM") && h.lds && !h.pf2 && h.cm == h.ipw && h.nt == 4 && ((h.mt == 1 && (!want_fuse || h.cm == 4)) || (h.mt == 2 && h.cm == 2));
+                    if (ok && h.w8) ok = !getenv("IRMV_NO_W8") && h.lds && op.cfg.stride == 2 && h.nt == 4 && !want_fuse && !h.pf2 && (h.mt == 1 || h.mt == 2) &&
+                                         (h.cm == 0 || (h.cm == h.ipw && ((h.mt == 2 && h.cm == 2) || (h.mt == 1 && h.cm == 4))));
+                    if (ok && !h.w8 && getenv("IRMV_FORCE_W8") && lds_ok && op.cfg.stride == 2) ok = false;
                     if (ok && !h.cm && getenv("IRMV_FORCE_CM") && lds_ok && counts[pass] >= 2) ok = false;   // parity tests: the chunk-major tiles wherever one exists
                     if (ok) {
                         best_cfg = op.cfg;
-                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct; best_cfg.pw = h.pw; best_cfg.pf2 = h.pf2; best_cfg.cm = h.cm;
+                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct; best_cfg.pw = h.pw; best_cfg.pf2 = h.pf2; best_cfg.cm = h.cm; best_cfg.w8 = h.w8;
                         best = 0.f;
                         have_hit = true;
                     } else if (getenv("IRMV_AUTOTUNE_VERBOSE") || getenv("IRMV_TUNE_WARN"))
@@ -1359,7 +1362,7 @@ static int autotune_convs(irmv_engine *e)
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             if (want_fuse && nt != 4) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = 0;
+                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false;
                             TRY(time_cfg(c));
                         }
                 // LDS family, smallest pixel tile, staging two steps ahead (layers whose step is shorter than a memory round trip)
@@ -1368,7 +1371,7 @@ static int autotune_convs(irmv_engine *e)
                         for (int ipw = 1; ipw <= std::min(4, counts[pass]); ipw *= 2) {
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = 1; c.nt = nt; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = true; c.cm = 0;
+                            c.mt = 1; c.nt = nt; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = true; c.cm = 0; c.w8 = false;
                             TRY(time_cfg(c));
                         }
                 // LDS family, chunk-major over the workgroup's images: a chunk's weights staged once for all of them
@@ -1377,14 +1380,26 @@ static int autotune_convs(irmv_engine *e)
                         for (int ipw = 2; ipw <= std::min(mt == 1 ? 4 : 2, counts[pass]); ipw *= 2) {
                             if (want_fuse && mt == 1 && ipw == 2) continue;   // (no instantiation with the fused 1x1)
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = ipw;
+                            c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = ipw; c.w8 = false;
                             TRY(time_cfg(c));
                             if (getenv("IRMV_FORCE_CM") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                         }
+                // LDS family, stride 2: one 8-wave workgroup per CU on a block twice as tall (mt = 2 fits LDS, weights staged for
+                // twice the pixels)
+                if (fam == 1 && op.cfg.stride == 2 && !want_fuse && op.cout_pad % 64 == 0 && !getenv("IRMV_NO_W8"))
+                    for (int mt = 1; mt <= 2; mt *= 2)
+                        for (int ipw = 1; ipw <= std::min(4, counts[pass]); ipw *= 2)
+                            for (int cmv = 0; cmv < 2; cmv++) {
+                                if (cmv && !((mt == 2 && ipw == 2) || (mt == 1 && ipw == 4))) continue;
+                                ConvCfg c = op.cfg;
+                                c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = cmv ? ipw : 0; c.w8 = true;
+                                TRY(time_cfg(c));
+                                if (getenv("IRMV_FORCE_W8") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
+                            }
                 // 1x1 layers: the persistent pointwise kernel (same operands, same k order as the direct kernel)
                 if (conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW")) {
                     ConvCfg c = op.cfg;
-                    c.mt = 2; c.nt = 4; c.lds = false; c.ipw = 1; c.deep = false; c.ct = false; c.pw = true; c.pf2 = false; c.cm = 0;
+                    c.mt = 2; c.nt = 4; c.lds = false; c.ipw = 1; c.deep = false; c.ct = false; c.pw = true; c.pf2 = false; c.cm = 0; c.w8 = false;
                     TRY(time_cfg(c));
                     if (getenv("IRMV_FORCE_PW") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                 }
@@ -1395,7 +1410,7 @@ static int autotune_convs(irmv_engine *e)
                         for (int nt = 1; nt <= 4; nt *= 2) {
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = nt; c.lds = false; c.ipw = 1; c.deep = false; c.ct = true; c.pw = false; c.pf2 = false; c.cm = 0;
+                            c.mt = mt; c.nt = nt; c.lds = false; c.ipw = 1; c.deep = false; c.ct = true; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false;
                             TRY(time_cfg(c));
                         }
                 // single-frame steps: the latency variants of the direct kernel (deep prefetch ring), same rule.
@@ -1406,7 +1421,7 @@ static int autotune_convs(irmv_engine *e)
                     for (auto &t : tiles) {
                         if (op.cout_pad % (16 * t[1]) != 0) continue;
                         ConvCfg c = op.cfg;
-                        c.mt = t[0]; c.nt = t[1]; c.lds = false; c.ipw = 1; c.deep = true; c.ct = lds_ok; c.pw = false; c.pf2 = false; c.cm = 0;
+                        c.mt = t[0]; c.nt = t[1]; c.lds = false; c.ipw = 1; c.deep = true; c.ct = lds_ok; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false;
                         TRY(time_cfg(c));
                     }
                 }

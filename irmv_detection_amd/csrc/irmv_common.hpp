@@ -180,6 +180,7 @@ struct ConvCfg {
     bool ct;     // direct kernel walking K chunk-major with the LDS family's weights: bit-identical stand-in for that family
     bool pw;     // 1x1 layers: the persistent pointwise kernel (weights in LDS, pixel tiles software-pipelined)
     bool pf2;    // LDS family, mt = 1: global -> register staging two (image, chunk) steps ahead instead of one
+    bool w8;     // LDS family, stride 2: one 8-wave workgroup on a block twice as tall (weights staged for twice the pixels, mt = 2 fits LDS)
     int cm;      // LDS family: chunk-major order over the workgroup's cm = ipw images (0: image-major), weights staged once per chunk
 };
 // returns false if no instantiation exists for cfg
@@ -194,7 +195,7 @@ bool launch_conv_direct_multi(const ConvCfg &cfg, const ConvArgs *a, int n, hipS
 bool launch_conv_pw(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 // LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt
 size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max);
-bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2 = false, int cm = 0);   // a.n2 > 0: fused 1x1 (needs stride 1, nt 4, cout 64); pf2: staging two steps ahead (mt = 1)
+bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2 = false, int cm = 0, bool w8 = false);   // a.n2 > 0: fused 1x1 (needs stride 1, nt 4, cout 64); pf2: staging two steps ahead (mt = 1)
 
 // SPPF pooling chain: slice 0 (C ch) of [B][H][W][4C] -> slices 1..3 (5x5, 9x9, 13x13 max)
 void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s);

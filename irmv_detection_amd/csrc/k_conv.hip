@@ -602,12 +602,13 @@ __device__ int g_stagger_sleeps = 0;
 #endif
 // The kernel's body as a device function of (workgroup index, grid size), so that one launch can serve several layers
 // (conv3x3_lds_multi below); conv3x3_lds_kernel itself is the thin wrapper behind it.
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4>
 __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch,
                                                  int wg_x, int wg_y, int grid_x, int grid_y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    constexpr int NTH = 64 * NWV;   // NWV waves stacked along pixels (4; 8 for the stride-2 layers' large block, see launch_conv_lds)
     const int g = lane >> 4, r = lane & 15;
     // Pixel ownership, two schemes:
     //  TILE2D  : a 2-D block.  An MFMA tile is (16 / TWc) rows x TWc columns, a wave stacks MT of them
@@ -635,7 +636,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     bool mv[MT];
     if constexpr (TILE2D) {
         const int TWc = 1 << twc_log2, trows = 16 >> twc_log2;
-        const int RH = 4 * MT * trows;
+        const int RH = NWV * MT * trows;
         const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
         const int y0 = tyi * RH, x0 = txi * TWc;
         PW = TWc * STRIDE + 2; PR = RH * STRIDE + 2;
@@ -649,7 +650,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
             poff[mt] = ((ly * STRIDE) * PW + lx * STRIDE) * pix_stride(STRIDE) + g * 16;
         }
     } else {
-        constexpr int TPX = 64 * MT;
+        constexpr int TPX = 16 * NWV * MT;
         const int m0 = tile * TPX, m1 = min(m0 + TPX, HWo);
         const int y0 = m0 / a.Wout, y1 = (m1 - 1) / a.Wout;
         PW = a.Win + 2; PR = (y1 - y0) * STRIDE + 3;
@@ -680,14 +681,14 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     }
     if constexpr (N2 > 0) {
         if (tid < N2 * 16) s_bias2[tid] = a.bias2[tid];
-        for (int e = tid; e < N2 * 2 * 64; e += 256) s_w2[e] = reinterpret_cast<const half8 *>(a.w2)[e];
+        for (int e = tid; e < N2 * 2 * 64; e += NTH) s_w2[e] = reinterpret_cast<const half8 *>(a.w2)[e];
     }
     const int chunks = a.Cin >> 5;
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 
     // staging plan: element e -> (patch pixel, 16-byte quarter); weights: 9*NT*64 half8 per chunk
     constexpr int PMAX = lds_pmax(STRIDE, MT, TILE2D);   // patch 16-B pieces per thread (host guarantees the fit)
-    constexpr int WPT = (9 * NT * 64 + 255) / 256; // weight half8 per thread
+    constexpr int WPT = (9 * NT * 64 + NTH - 1) / NTH; // weight half8 per thread
     const int n_pe = PR * PW * 4;
     const float inv_pw = 1.0f / (float)PW;
     const half_t *src_p[PMAX];
@@ -695,12 +696,12 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     bool val_p[PMAX], use_p[PMAX];
 #pragma unroll
     for (int i = 0; i < PMAX; i++) {
-        const int e = tid + i * 256;
+        const int e = tid + i * NTH;
         use_p[i] = e < n_pe;
         val_p[i] = false;
         src_p[i] = a.s0.p;
         dst_p[i] = 0;
-        if (i * 256 >= n_pe) continue;                     // wave-uniform: this piece slot is unused by the whole workgroup
+        if (i * NTH >= n_pe) continue;                     // wave-uniform: this piece slot is unused by the whole workgroup
         const int pix = use_p[i] ? (e >> 2) : 0, q = e & 3;
         int pr = (int)((float)pix * inv_pw);               // pix < 2^16: one correction step makes the quotient exact
         pr -= (pr * PW > pix) ? 1 : 0;
@@ -738,7 +739,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         for (int i = 0; i < WPT; i++) {
             if ((IRMV_ABL & 1) && (l_im | l_chunk)) break;
             if (CM > 0 && l_im != 0) break;                // chunk-major: the chunk's weights are in LDS already
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             if (e < 9 * NT * 64) w[i] = wsrc[(size_t)l_chunk * (9 * NT * 64) + e];
         }
         if constexpr (CM > 0) {
@@ -757,7 +758,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         for (int i = 0; i < WPT; i++) {
             if ((IRMV_ABL & 1) && (c_im | c_chunk)) break;
             if (CM > 0 && c_im != 0) break;
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             if (e < 9 * NT * 64) s_w[e] = w[i];
         }
     };
@@ -925,7 +926,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
                         rp[0][j] = zero8;
                         if (val_p[j]) rp[0][j] = *reinterpret_cast<const half8 *>(src_p[j] + off);
                     } else if (j < NPIECE) {
-                        const int e = tid + (j - PMAX) * 256;
+                        const int e = tid + (j - PMAX) * NTH;
                         if (e < 9 * NT * 64) rw[0][j - PMAX] = wsrc[(size_t)l_chunk * (9 * NT * 64) + e];
                     }
                 }
@@ -1083,10 +1084,10 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     }
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
 {
-    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2, CM>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // Several independent 3x3 layers in ONE launch (the Detect branches of the three levels in a single-frame step: fifteen
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
 // block tiles the image exactly (no masked lanes); otherwise the row-run scheme.  bytes == 0: not eligible.
 struct LdsGeom { bool tile2d; int tiles_x, tiles_y, twc_log2, patch_bytes; size_t bytes; };
 
-static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt)
+static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt, int nwv = 4)
 {
     LdsGeom g{false, 0, 0, 0, 0, 0};
     if (a.Cin % 32 != 0 || a.s1.C != 0 || a.s0.shift != 0) return g;
@@ -1122,7 +1123,7 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt)
     if (a.cout_pad % (16 * nt) != 0) return g;
     int pr, pw;
     const int l2 = a.Wout % 16 == 0 ? 4 : (a.Wout % 8 == 0 ? 3 : (a.Wout % 4 == 0 ? 2 : -1));
-    const int rh = l2 >= 0 ? 4 * mt * (16 >> l2) : 0;
+    const int rh = l2 >= 0 ? nwv * mt * (16 >> l2) : 0;
     if (l2 >= 0 && a.Hout % rh == 0) {
         g.tile2d = true;
         g.twc_log2 = l2;
@@ -1131,17 +1132,17 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt)
         pr = rh * stride + 2;
         pw = (1 << l2) * stride + 2;
     } else {
-        const int tpx = 64 * mt;
+        const int tpx = 16 * nwv * mt;
         g.tiles_x = (a.Hout * a.Wout + tpx - 1) / tpx;
         g.tiles_y = 1;
         const int rows = (tpx + a.Wout - 2) / a.Wout + 1;      // most output rows a run of tpx pixels can touch
         pr = (rows - 1) * stride + 3;
         pw = a.Win + 2;
     }
-    if ((size_t)pr * pw * 4 > (size_t)lds_pmax(stride, mt, g.tile2d) * 256) return g;   // staging plan: pieces per thread
+    if ((size_t)pr * pw * 4 > (size_t)lds_pmax(stride, mt, g.tile2d) * 64 * nwv) return g;   // staging plan: pieces per thread
     g.patch_bytes = pr * pw * pix_stride(stride);
     const size_t bytes = (size_t)g.patch_bytes + (size_t)9 * nt * 1024 + 512 + (size_t)a.n2 * 2048;   // + bias, bias2, fused 1x1 fragments
-    if (bytes > 80 * 1024) return g;                            // two or more workgroups per CU
+    if (bytes > (size_t)(nwv == 8 ? 150 : 80) * 1024) return g;   // two or more 4-wave workgroups per CU, or one of 8 waves
     g.bytes = bytes;
     return g;
 }
@@ -1153,23 +1154,37 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
     return g.bytes;
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4>
 static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int ipw, const LdsGeom &g, hipStream_t s)
 {
     static unsigned long long attr_done = 0;   // per instantiation: devices whose dynamic-LDS limit has been raised
     once_per_device(attr_done, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int groups = (batch + ipw - 1) / ipw;
-    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(256), g.bytes, s, a,
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(64 * NWV), g.bytes, s, a,
                        wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch);
 }
 
-bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2, int cm)
+bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2, int cm, bool w8)
 {
+    if (ipw < 1) ipw = 1;
+    if (w8) {   // stride-2 layers: ONE 8-wave workgroup per CU on a block of 128 mt pixels -- see DESIGN section 4
+        if (stride != 2 || nt != 4 || a.n2 > 0 || pf2 || (cm && cm != ipw)) return false;
+        const LdsGeom g8 = lds_geom(a, stride, mt, nt, 8);
+        if (!g8.bytes) return false;
+#define IRMV_LDS_W8(MT_, CM_)                                                                            \
+        if (mt == MT_ && cm == CM_) {                                                                    \
+            if (g8.tile2d) launch_lds_inst<2, MT_, 4, true, 0, false, CM_, 8>(a, wl, batch, ipw, g8, s); \
+            else launch_lds_inst<2, MT_, 4, false, 0, false, CM_, 8>(a, wl, batch, ipw, g8, s);          \
+            return true;                                                                                 \
+        }
+        IRMV_LDS_W8(2, 0) IRMV_LDS_W8(2, 2) IRMV_LDS_W8(1, 0) IRMV_LDS_W8(1, 4)
+#undef IRMV_LDS_W8
+        return false;
+    }
     const LdsGeom g = lds_geom(a, stride, mt, nt);
     if (!g.bytes) return false;
-    if (ipw < 1) ipw = 1;
     if (cm) {   // chunk-major order over the workgroup's cm = ipw images (16 cm mt nt accumulator registers)
         if (cm != ipw || pf2) return false;
         if (a.n2 > 0 && (stride != 1 || nt != 4 || a.cout_pad != 64 || !a.pair || a.res)) return false;

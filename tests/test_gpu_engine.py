@@ -419,31 +419,39 @@ def test_pointwise_kernel_is_bitwise_the_direct_kernel(blob, monkeypatch):
     assert np.array_equal(heads["IRMV_FORCE_PW"][1], heads["IRMV_FORCE_PW"][3])
 
 
-def test_chunk_major_tiles_are_bitwise_the_image_major_ones(blob, monkeypatch):
-    """LDS 3x3 family, chunk-major order over a workgroup's images (a chunk's weights staged once, one accumulator set per
-    image; k_conv.hip CM) against the image-major order it may replace: every output sees the same MFMA sequence -> same
-    bits.  Six frames in one sub-batch: groups of four leave a short last group (two images), groups of two three full ones."""
+def test_chunk_major_and_eight_wave_tiles_are_bitwise_the_plain_ones(blob, monkeypatch):
+    """LDS 3x3 family: chunk-major order over a workgroup's images (a chunk's weights staged once, one accumulator set per
+    image; k_conv.hip CM) and the stride-2 layers' 8-wave workgroup (NWV = 8) against the image-major 4-wave kernels they
+    may replace: every output sees the same MFMA sequence -> same bits.  Six frames in one sub-batch: groups of four leave
+    a short last group (two images), groups of two three full ones."""
     imgs = [frames.synthetic_frame(60 + i) for i in range(6)]
     heads = {}
-    for mode in ("IRMV_FORCE_CM", "IRMV_NO_CM"):
-        monkeypatch.delenv("IRMV_FORCE_CM", raising=False)
-        monkeypatch.delenv("IRMV_NO_CM", raising=False)
+    modes = ("IRMV_FORCE_CM", "IRMV_FORCE_W8", "IRMV_NO_CM")
+    for mode in modes:
+        for m in modes + ("IRMV_NO_W8",):
+            monkeypatch.delenv(m, raising=False)
         monkeypatch.setenv(mode, "1")
+        if mode == "IRMV_NO_CM":
+            monkeypatch.setenv("IRMV_NO_W8", "1")
         with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=6, num_streams=1) as e:
             names = [st["name"] for st in e.profile(0, 6)]
-            n_cm = sum("_cm" in n for n in names)
-            assert (n_cm >= 10) if mode == "IRMV_FORCE_CM" else (n_cm == 0), (mode, names)
+            n_cm, n_w8 = sum("_cm" in n for n in names), sum("_w8" in n for n in names)
             if mode == "IRMV_FORCE_CM":
-                assert any(n.endswith("_i4_cm") for n in names) and any("_cm+1x1" in n for n in names), names
+                assert n_cm >= 10 and any("_i4_cm" in n for n in names) and any("_cm+1x1" in n for n in names), names
+            elif mode == "IRMV_FORCE_W8":
+                assert n_w8 == 5, names                      # the five stride-2 convs
+            else:
+                assert n_cm == 0 and n_w8 == 0, names
             for s, im in enumerate(imgs):
                 _load(e, s, im)
             e.submit(0, 6); e.wait()
             heads[mode] = [e.read_head(s).copy() for s in range(6)]
             heads[mode + "_taps"] = {t: e.read_tap(t, 5).copy() for t in ("3", "5", "7", "16", "19", "21")}   # the stride-2 convs' outputs, last slot
-    for a, b in zip(heads["IRMV_FORCE_CM"], heads["IRMV_NO_CM"]):
-        assert np.array_equal(a, b)
-    for k, v in heads["IRMV_FORCE_CM_taps"].items():
-        assert np.array_equal(v, heads["IRMV_NO_CM_taps"][k]), k
+    for mode in modes[:2]:
+        for a, b in zip(heads[mode], heads["IRMV_NO_CM"]):
+            assert np.array_equal(a, b), mode
+        for k, v in heads[mode + "_taps"].items():
+            assert np.array_equal(v, heads["IRMV_NO_CM_taps"][k]), (mode, k)
 
 
 def test_merged_head_first_stage_is_bitwise_the_separate_convs(blob, frame0, monkeypatch):
