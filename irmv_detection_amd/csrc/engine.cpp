@@ -1305,7 +1305,7 @@ static int autotune_convs(irmv_engine *e)
                     if (!h.pw && getenv("IRMV_FORCE_PW") && conv_pw_eligible(op.cfg, a)) ok = false;                                  // (parity tests)
                     if (ok && h.lds) {
                         const int li = h.nt == 4 ? 2 : (h.nt == 2 ? 1 : 0);
-                        ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, h.mt, h.nt, nullptr) > 0;
+                        ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, h.mt, h.nt, nullptr, h.w8) > 0;
                     }
                     if (ok && !h.lds) ok = h.ipw == 1;
                     if (ok && h.deep) ok = (h.mt == 1 || (h.mt == 2 && h.nt == 1)) && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1;

@@ -194,7 +194,7 @@ bool launch_conv_lds_multi(int nt, const ConvArgs *a, const half_t *const *wl, i
 bool launch_conv_direct_multi(const ConvCfg &cfg, const ConvArgs *a, int n, hipStream_t s);
 bool launch_conv_pw(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 // LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt
-size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max);
+size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max, bool w8 = false);
 bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2 = false, int cm = 0, bool w8 = false);   // a.n2 > 0: fused 1x1 (needs stride 1, nt 4, cout 64); pf2: staging two steps ahead (mt = 1)
 
 // SPPF pooling chain: slice 0 (C ch) of [B][H][W][4C] -> slices 1..3 (5x5, 9x9, 13x13 max)

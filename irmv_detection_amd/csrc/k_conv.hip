@@ -1147,9 +1147,9 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt, int nwv =
     return g;
 }
 
-size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max)
+size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max, bool w8)
 {
-    const LdsGeom g = lds_geom(a, stride, mt, nt);
+    const LdsGeom g = lds_geom(a, stride, mt, nt, w8 ? 8 : 4);
     if (patch_rows_max) *patch_rows_max = g.patch_bytes;
     return g.bytes;
 }

@@ -551,6 +551,11 @@ def test_benchmarked_configuration_is_bitwise_the_single_slot_engine(blob, onet,
         assert e.num_streams == 3
         names = [st["name"] for st in e.profile(0, B // 3)]
         assert any("_i4" in n or "_i2" in n for n in names), names       # several images per workgroup are in play
+        # the committed table's special tiles are REPLAYED, not silently re-tuned (a cached tile that fails validation is)
+        import bench
+        flags = [int(l.split()[-2]) for l in open(bench.tune_cache_seed()) if "|n64|" in l]
+        assert any(f & (64 | 128) for f in flags) == any("_cm" in n for n in names), names
+        assert any(f & 256 for f in flags) == any("_w8" in n for n in names), names
         for s in range(B):
             _load(e, s, imgs[s])
         e.submit(0, B, h2d=True)
