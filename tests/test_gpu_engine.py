@@ -454,6 +454,28 @@ def test_chunk_major_and_eight_wave_tiles_are_bitwise_the_plain_ones(blob, monke
             assert np.array_equal(v, heads["IRMV_NO_CM_taps"][k]), (mode, k)
 
 
+def test_eight_wave_tiles_on_maps_that_do_not_tile(blob, monkeypatch):
+    """The stride-2 layers' 8-wave workgroup on a 416 net: 52 x 52, 26 x 26 and 13 x 13 outputs take the row-run block
+    scheme (no 2-D block divides them), last blocks are partial, the batch's last image group is short (three frames)."""
+    imgs = [frames.synthetic_frame(80 + i) for i in range(3)]
+    heads = {}
+    for mode in ("IRMV_FORCE_W8", "IRMV_NO_W8"):
+        for m in ("IRMV_FORCE_W8", "IRMV_NO_W8", "IRMV_NO_CM"):
+            monkeypatch.delenv(m, raising=False)
+        monkeypatch.setenv(mode, "1")
+        if mode == "IRMV_NO_W8":
+            monkeypatch.setenv("IRMV_NO_CM", "1")
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3, num_streams=1, net_size=416) as e:
+            names = [st["name"] for st in e.profile(0, 3)]
+            assert (sum("_w8" in n for n in names) == 5) == (mode == "IRMV_FORCE_W8"), (mode, names)
+            for s, im in enumerate(imgs):
+                _load(e, s, im)
+            e.submit(0, 3); e.wait()
+            heads[mode] = [e.read_head(s).copy() for s in range(3)] + [e.read_tap(t, 2).copy() for t in ("3", "5", "7", "16", "19")]
+    for a, b in zip(heads["IRMV_FORCE_W8"], heads["IRMV_NO_W8"]):
+        assert np.array_equal(a, b)
+
+
 def test_merged_head_first_stage_is_bitwise_the_separate_convs(blob, frame0, monkeypatch):
     """Single-frame engines run the three first-stage Detect convs of a level as one conv (weights concatenated along
     cout, second-stage convs reading channel slices): same bits as the separate convs, for pose and bbox-only models."""
