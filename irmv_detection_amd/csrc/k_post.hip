@@ -576,13 +576,15 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     IRMV_STAMP(1);
 
     constexpr int kMatN = 512, kMatW = kMatN / 64;   // up to this many candidates the FULL suppression matrix fits ssup
+    constexpr int kLazyN = 1024, kLazyW = kLazyN / 64;   // up to this many: the matrix one 64-candidate block of rows at a time
+    __shared__ unsigned long long s_keptw[kLazyW];        // per 64-candidate block: its survivors
+    __shared__ unsigned long long s_clsmask[16][kLazyW];  // per class and block: which candidates have that class
     if (n <= kMatN) {
         // ---- 2'. full suppression matrix ----
         // Every IoU test the greedy walk can need, evaluated up front by the whole workgroup; the walk itself is then
         // AND / readlane work on 64-bit words (no boxes, no per-class kept lists).  Same comparisons as the oracle's walk.
         f32x4 *cbox = &stage_box[0][0];      // [1024] -> candidate boxes / classes in sorted order
         int *ccls = &stage_cls[0][0];
-        __shared__ unsigned long long s_keptw[kMatW];   // per 64-candidate block: its survivors
         for (int i = tid; i < ((n + 63) & ~63); i += blockDim.x) {
             if (i < n) {
                 const uint32_t id = 0xffffffffu - (uint32_t)(sorted[i] & 0xffffffffu);
@@ -597,7 +599,6 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         const int nw = (n + 63) >> 6;
         // per class and 64-candidate word: which candidates have that class (one ballot per class and wave) -- the class
         // filter of the matrix rows below is then ONE 8-byte LDS read per word instead of sixteen 16-byte ones
-        __shared__ unsigned long long s_clsmask[16][kMatW];
         if (wave < kMatW) {
             const int c = tid < (nw << 6) ? ccls[tid] : -1;
             for (int k = 0; k < a.nc; k++) {
@@ -683,6 +684,89 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         if (wave == 0) {
             const int kept = walk_blocks(0, nw, 0);
             if (lane == 0) s_kept = kept;
+        }
+    } else if (n <= kLazyN) {
+        // ---- 2'' / 3''. crowded frames (513 .. 1024 candidates): the same matrix rows, built one 64-candidate block at a time
+        // right before the walk reaches that block, and not at all once max_det survivors are found.  (A frame with 900
+        // candidates fills max_det = 100 in its first few hundred; the all-pairs matrix would run 6 x the IoU tests of a
+        // 380-candidate frame, and the per-class-list walk below it took 85 us on such frames.)
+        f32x4 *cbox = &stage_box[0][0];
+        int *ccls = &stage_cls[0][0];
+        for (int i = tid; i < ((n + 63) & ~63); i += blockDim.x) {
+            if (i < n) {
+                const uint32_t id = 0xffffffffu - (uint32_t)(sorted[i] & 0xffffffffu);
+                cbox[i] = boxes[anchor_of(id, a.nc, a.A)];
+                ccls[i] = (int)(id % (uint32_t)a.nc);
+            } else {
+                ccls[i] = -1;
+            }
+        }
+        if (tid < kLazyW) s_keptw[tid] = 0ull;
+        if (tid == 0) s_kept = 0;
+        __syncthreads();
+        const int nw = (n + 63) >> 6;
+        {
+            const int c = tid < (nw << 6) ? ccls[tid] : -1;        // 16 waves = 16 blocks of 64
+            for (int k = 0; k < a.nc; k++) {
+                const unsigned long long mk = __ballot(c == k);
+                if (lane == 0) s_clsmask[k][wave] = mk;
+            }
+        }
+        __syncthreads();
+        uint32_t *rows32 = reinterpret_cast<uint32_t *>(ssup);     // [64 rows][kLazyW words][2 halves] of the current block
+        IRMV_STAMP(2);
+        for (int blk = 0; blk < nw; blk++) {
+            if (s_kept >= a.max_det) break;                        // workgroup-uniform (read behind the barrier below)
+            for (int item = tid; item < 128 * (blk + 1); item += blockDim.x) {
+                const int h = item & 1, row = (item >> 1) & 63, w = item >> 7;
+                const int i = (blk << 6) + row;
+                uint32_t mask = 0u;
+                const int j0 = (w << 6) + (h << 5);
+                if (i < n && j0 < i) {
+                    const f32x4 bi = cbox[i];
+                    const int jend = i - j0 < 32 ? i - j0 : 32;
+                    uint32_t same = (uint32_t)(s_clsmask[ccls[i]][w] >> (h << 5));
+                    if (jend < 32) same &= (1u << jend) - 1u;
+                    while (same) {
+                        const int jj = __ffs((int)same) - 1;
+                        same &= same - 1u;
+                        if (iou_gt(cbox[j0 + jj], bi, a.iou_thr)) mask |= 1u << jj;
+                    }
+                }
+                rows32[(row * kLazyW + w) * 2 + h] = mask;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int kept = s_kept;
+                const int idx = (blk << 6) + lane;
+                const bool valid = idx < n;
+                bool alive = valid;
+                for (int w = 0; w < blk; w++)
+                    if (valid && (ssup[lane * kLazyW + w] & s_keptw[w]) != 0ull) alive = false;
+                const unsigned long long sup = valid ? ssup[lane * kLazyW + blk] : 0ull;
+                unsigned long long U = __ballot(alive), K = 0ull;   // undecided, kept (rounds: see the matrix path above)
+                while (U) {
+                    const bool ready = ((U >> lane) & 1ull) && (sup & U) == 0ull;
+                    const unsigned long long R = __ballot(ready);
+                    K |= __ballot(ready && (sup & K) == 0ull);
+                    U &= ~R;
+                }
+                const int room = a.max_det - kept;
+                unsigned long long A = K;
+                if (__popcll(K) > room) {
+                    const bool over = ((K >> lane) & 1ull) && __popcll(K & ((1ull << lane) - 1ull)) >= room;
+                    A = K & ~__ballot(over);
+                }
+                const bool mine = (A >> lane) & 1ull;
+                const int pos = kept + __popcll(A & ((1ull << lane) - 1ull));
+                if (mine) {
+                    kept_box[pos] = cbox[idx];
+                    kept_cls[pos] = ccls[idx];
+                    kept_key[pos] = sorted[idx];
+                }
+                if (lane == 0) { s_keptw[blk] = A; s_kept = kept + __popcll(A); }
+            }
+            __syncthreads();
         }
     } else {
     // ---- 2. intra-block masks, one block per wave ----

@@ -165,7 +165,8 @@ def test_post_exact_on_oracle_heads(eng, onet):
         assert (np.diff(raw["scores"]) <= 0).all()
 
 
-@pytest.mark.parametrize("hot,expect", [(0.0, "empty"), (0.00002, "few"), (0.004, "typical"), (0.03, "more_than_pre_nms_cap_is_fine")])
+@pytest.mark.parametrize("hot,expect", [(0.0, "empty"), (0.00002, "few"), (0.004, "typical"), (0.0055, "crowded"), (0.008, "crowded"),
+                                        (0.03, "more_than_pre_nms_cap_is_fine")])
 def test_post_exact_on_synthetic_heads(eng, hot, expect):
     rng = np.random.default_rng(int(hot * 1e6) + 1)
     head = _synthetic_head(rng, hot)
@@ -174,6 +175,8 @@ def test_post_exact_on_synthetic_heads(eng, hot, expect):
     raw = _assert_post_exact(eng, head)
     if expect == "empty":
         assert raw["num_dets"] == 0 and raw["n_candidates"] == 0
+    if expect == "crowded":                              # 513 .. 1024 candidates: the matrix one block of rows at a time
+        assert 512 < raw["n_candidates"] <= 1024
     if expect == "more_than_pre_nms_cap_is_fine":
         assert 2500 < raw["n_candidates"] <= capi.CAND_CAP
 
@@ -211,7 +214,7 @@ def test_more_candidates_than_the_lds_sort_holds(eng):
     eng.results(0)                                      # no overflow error any more
 
 
-@pytest.mark.parametrize("cap", [100, 300, 512, 513, 2048])
+@pytest.mark.parametrize("cap", [100, 300, 512, 513, 800, 1024, 1025, 2048])
 def test_more_candidates_than_the_lds_sort_holds_small_pre_nms_cap(blob, cap):
     """> 8192 candidates AND pre_nms_cap <= 512: the radix-selected keys go through the rank sort, which must sort the
     SELECTED keys (round 1 re-read the first K raw keys there).  513 / 2048: the bitonic branch after a select."""
