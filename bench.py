@@ -47,7 +47,7 @@ PEAK_HBM_GBS = 8000.0
 
 def tune_cache_seed():
     """Committed autotuner table the bench (and the test of the benchmarked configuration) replays: newest round first."""
-    for name in ("r02_tune_cache.txt", "r01_tune_cache.txt"):
+    for name in ("r03_tune_cache.txt", "r02_tune_cache.txt", "r01_tune_cache.txt"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             return p

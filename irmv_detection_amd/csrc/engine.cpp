@@ -185,6 +185,7 @@ struct irmv_engine {
     irmv_engine_cfg cfg{};
     int nc = 0, nk = 0, A = 0, no = 0;
     int backbone = 0;   // 0: C2f stages (YOLOv8n), 1: ShuffleNetV2 stages (blob header)
+    int num_cus = 256;  // compute units of the device (persistent kernels size their grids by it)
     // Single-frame engines: the independent Detect-branch convs of the three levels as one launch per stage (k_conv.hip
     // conv3x3_lds_multi / conv_mfma_multi).  family 0: LDS 3x3 with tile (mt 1, nt); 1: direct kernel with cfg.
     struct HeadGroup { std::vector<int> members; int family = 0, nt = 1; ConvCfg cfg{}; char name[48] = {0}; };
@@ -1146,6 +1147,10 @@ extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
     if (cfg->device < 0 || cfg->device >= ndev) return fail(IRMV_ERR_HIP, "no such HIP device");
     std::unique_ptr<irmv_engine> e(new irmv_engine);
     e->cfg = *cfg;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) e->num_cus = cus;
+    }
     int rc = load_blob(e.get());
     e->cfg.weights_path = nullptr;  // caller-owned, not retained
     e->cfg.weights_blob = nullptr;
@@ -1200,7 +1205,7 @@ static void tune_cache_load()
     int mt, nt, lds, ipw;
     while (f >> key >> mt >> nt >> lds >> ipw) {
         ConvCfg c{};
-        c.mt = mt; c.nt = nt; c.lds = (lds & 1) != 0; c.deep = (lds & 2) != 0; c.ct = (lds & 4) != 0; c.pw = (lds & 8) != 0; c.pf2 = (lds & 16) != 0; c.cm = (lds & 64) ? 2 : ((lds & 128) ? 4 : 0); c.w8 = (lds & 256) != 0; c.ipw = ipw;   // bit 0 LDS family, 1 deep prefetch, 2 direct kernel in the LDS family's K order, 3 pointwise kernel, 4 two-step staging, 6 / 7 LDS family chunk-major over 2 / 4 images, 8 LDS family 8-wave workgroup
+        c.mt = mt; c.nt = nt; c.lds = (lds & 1) != 0; c.deep = (lds & 2) != 0; c.ct = (lds & 4) != 0; c.pw = (lds & 8) != 0; c.pf2 = (lds & 16) != 0; c.cm = (lds & 64) ? 2 : ((lds & 128) ? 4 : 0); c.w8 = (lds & 256) != 0; c.wr = (lds & 512) != 0; c.pp = (lds & 1024) != 0; c.ipw = ipw;   // bit 0 LDS family, 1 deep prefetch, 2 direct kernel in the LDS family's K order, 3 pointwise kernel, 4 two-step staging, 6 / 7 LDS family chunk-major over 2 / 4 images, 8 LDS family 8-wave workgroup, 9 LDS family with resident weights (ipw = images per workgroup, any value), 10 its ping-pong form
         g_tune_cache[key] = c;
     }
 }
@@ -1212,13 +1217,14 @@ static void tune_cache_save()
     std::lock_guard<std::mutex> lk(g_tune_mu);
     std::ofstream f(path);
     for (auto &kv : g_tune_cache)
-        f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0) | (kv.second.pw ? 8 : 0) | (kv.second.pf2 ? 16 : 0) | (kv.second.cm == 2 ? 64 : 0) | (kv.second.cm == 4 ? 128 : 0) | (kv.second.w8 ? 256 : 0)) << ' ' << kv.second.ipw << '\n';
+        f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0) | (kv.second.pw ? 8 : 0) | (kv.second.pf2 ? 16 : 0) | (kv.second.cm == 2 ? 64 : 0) | (kv.second.cm == 4 ? 128 : 0) | (kv.second.w8 ? 256 : 0) | (kv.second.wr ? 512 : 0) | (kv.second.pp ? 1024 : 0)) << ' ' << kv.second.ipw << '\n';
 }
 
 static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int count, hipStream_t s)
 {
     const int li = c.nt == 4 ? 2 : (c.nt == 2 ? 1 : 0);
     if (c.pw) return launch_conv_pw(c, a, s);
+    if (c.wr) return c.lds && op.w_lds[2] && launch_conv_wres(c.ipw, a, op.w_lds[2], count, s, c.pp);
     if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s, c.pf2, c.cm, c.w8);
     if (c.ct) {   // direct kernel in the LDS family's K order, on that family's nt = 1 weight packing
         if (!op.w_lds[0] || a.n2 > 0) return false;
@@ -1232,6 +1238,7 @@ static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int coun
 static void cfg_name(const ConvCfg &c, char *buf, int n)
 {
     if (c.pw) snprintf(buf, n, "conv1x1s1_pw");
+    else if (c.wr) snprintf(buf, n, "conv3x3s1_wres%s_i%d", c.pp ? "_pp" : "", c.ipw);
     else if (c.lds && c.ipw > 1) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d_i%d%s%s", c.stride, c.mt, c.nt, c.ipw, c.cm ? "_cm" : (c.pf2 ? "_p2" : ""), c.w8 ? "_w8" : "");
     else if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d%s%s", c.stride, c.mt, c.nt, c.pf2 ? "_p2" : "", c.w8 ? "_w8" : "");
     else conv_cfg_name(c, buf, n);
@@ -1296,17 +1303,19 @@ static int autotune_convs(irmv_engine *e)
                 auto hit = g_tune_cache.find(key);
                 if (hit != g_tune_cache.end() && !verbose) {
                     const ConvCfg &h = hit->second;
-                    const bool pow2 = (h.mt == 1 || h.mt == 2 || h.mt == 4) && (h.nt == 1 || h.nt == 2 || h.nt == 4) && (h.ipw == 1 || h.ipw == 2 || h.ipw == 4);
+                    const bool pow2 = (h.mt == 1 || h.mt == 2 || h.mt == 4) && (h.nt == 1 || h.nt == 2 || h.nt == 4) && (h.ipw == 1 || h.ipw == 2 || h.ipw == 4 || (h.wr && h.ipw >= 1));
                     // family: LDS-staged, or (single-frame steps only) its chunk-major stand-in on the direct kernel; never both flags
                     const bool fam_ok = lds_ok ? ((h.lds && !h.ct && !h.deep) || (!h.lds && h.ct && !want_fuse && (!h.deep || counts[pass] == 1)))
                                                : (!h.lds && !h.ct && (!h.deep || counts[pass] == 1 || op.cfg.ks == 1));
                     bool ok = pow2 && op.cout_pad % (16 * h.nt) == 0 && h.ipw <= counts[pass] && fam_ok && (!want_fuse || h.nt == 4);
                     if (h.pw) ok = !h.lds && !h.ct && !h.deep && h.ipw == 1 && conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW");   // one tile shape
                     if (!h.pw && getenv("IRMV_FORCE_PW") && conv_pw_eligible(op.cfg, a)) ok = false;                                  // (parity tests)
-                    if (ok && h.lds) {
+                    if (ok && h.lds && !h.wr) {
                         const int li = h.nt == 4 ? 2 : (h.nt == 2 ? 1 : 0);
                         ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, h.mt, h.nt, nullptr, h.w8) > 0;
                     }
+                    if (ok && h.wr) ok = !getenv("IRMV_NO_WRES") && h.lds && !h.pf2 && !h.cm && !h.w8 && h.mt == 2 && h.nt == 4 && op.w_lds[2] && conv_wres_bytes(a, op.cfg.stride, h.pp) > 0;
+                    if (ok && getenv("IRMV_FORCE_WRES") && lds_ok && op.w_lds[2] && counts[pass] >= 2 && conv_wres_bytes(a, op.cfg.stride, false) > 0) ok = false;   // parity tests: always the forced form
                     if (ok && !h.lds) ok = h.ipw == 1;
                     if (ok && h.deep) ok = (h.mt == 1 || (h.mt == 2 && h.nt == 1)) && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1;
                     if (ok && h.ct) ok = op.w_lds[0] != nullptr;
@@ -1318,7 +1327,7 @@ static int autotune_convs(irmv_engine *e)
                     if (ok && !h.cm && getenv("IRMV_FORCE_CM") && lds_ok && counts[pass] >= 2) ok = false;   // parity tests: the chunk-major tiles wherever one exists
                     if (ok) {
                         best_cfg = op.cfg;
-                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct; best_cfg.pw = h.pw; best_cfg.pf2 = h.pf2; best_cfg.cm = h.cm; best_cfg.w8 = h.w8;
+                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct; best_cfg.pw = h.pw; best_cfg.pf2 = h.pf2; best_cfg.cm = h.cm; best_cfg.w8 = h.w8; best_cfg.wr = h.wr; best_cfg.pp = h.pp;
                         best = 0.f;
                         have_hit = true;
                     } else if (getenv("IRMV_AUTOTUNE_VERBOSE") || getenv("IRMV_TUNE_WARN"))
@@ -1362,7 +1371,7 @@ static int autotune_convs(irmv_engine *e)
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             if (want_fuse && nt != 4) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false;
+                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                             TRY(time_cfg(c));
                         }
                 // LDS family, smallest pixel tile, staging two steps ahead (layers whose step is shorter than a memory round trip)
@@ -1371,7 +1380,7 @@ static int autotune_convs(irmv_engine *e)
                         for (int ipw = 1; ipw <= std::min(4, counts[pass]); ipw *= 2) {
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = 1; c.nt = nt; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = true; c.cm = 0; c.w8 = false;
+                            c.mt = 1; c.nt = nt; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = true; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                             TRY(time_cfg(c));
                         }
                 // LDS family, chunk-major over the workgroup's images: a chunk's weights staged once for all of them
@@ -1380,7 +1389,7 @@ static int autotune_convs(irmv_engine *e)
                         for (int ipw = 2; ipw <= std::min(mt == 1 ? 4 : 2, counts[pass]); ipw *= 2) {
                             if (want_fuse && mt == 1 && ipw == 2) continue;   // (no instantiation with the fused 1x1)
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = ipw; c.w8 = false;
+                            c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = ipw; c.w8 = false; c.wr = false; c.pp = false;
                             TRY(time_cfg(c));
                             if (getenv("IRMV_FORCE_CM") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                         }
@@ -1392,14 +1401,41 @@ static int autotune_convs(irmv_engine *e)
                             for (int cmv = 0; cmv < 2; cmv++) {
                                 if (cmv && !((mt == 2 && ipw == 2) || (mt == 1 && ipw == 4))) continue;
                                 ConvCfg c = op.cfg;
-                                c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = cmv ? ipw : 0; c.w8 = true;
+                                c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = cmv ? ipw : 0; c.w8 = true; c.wr = false; c.pp = false;
                                 TRY(time_cfg(c));
                                 if (getenv("IRMV_FORCE_W8") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                             }
+                // LDS family, Cin = Cout = 64, stride 1: resident weights (one 8-wave workgroup per CU walks ipw images at its tile
+                // position; lockstep, or as two ping-pong groups of four waves).  ipw: the smallest that lets the chip hold the
+                // grid in one round, and half of it.
+                if (fam == 1 && counts[pass] >= 2 && op.w_lds[2] && !getenv("IRMV_NO_WRES"))
+                    for (int ppv = 0; ppv < 2; ppv++) {
+                        const int wgt = conv_wres_tiles(a, op.cfg.stride, ppv != 0);
+                        if (wgt <= 0) continue;
+                        int ipw1 = 1;
+                        while (ipw1 < counts[pass] && (long)wgt * ((counts[pass] + ipw1 - 1) / ipw1) > e->num_cus) ipw1++;
+                        const int cand[3] = {ipw1, (ipw1 + 1) / 2, std::min(counts[pass], 2 * ipw1)};
+                        for (int k = 0; k < 3; k++) {
+                            if (k > 0 && (cand[k] == cand[0] || (k == 2 && cand[2] == cand[1]))) continue;
+                            ConvCfg c = op.cfg;
+                            c.mt = 2; c.nt = 4; c.lds = true; c.ipw = cand[k]; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = true; c.pp = ppv != 0;
+                            TRY(time_cfg(c));
+                        }
+                    }
+                // parity tests: IRMV_FORCE_WRES=<n> puts every eligible layer on the resident-weights kernel with n images per
+                // workgroup -- the ping-pong form where the map tiles into its blocks (n < 0: never), else the lockstep form
+                if (const char *fw = getenv("IRMV_FORCE_WRES"); fw && fam == 1 && counts[pass] >= 2 && op.w_lds[2]) {
+                    const int v = atoi(fw);
+                    for (int ppv = v > 0 ? 1 : 0; ppv >= 0; ppv--) {
+                        ConvCfg c = op.cfg;
+                        c.mt = 2; c.nt = 4; c.lds = true; c.ipw = std::max(1, std::min(counts[pass], v < 0 ? -v : v)); c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = true; c.pp = ppv != 0;
+                        if (conv_wres_bytes(a, op.cfg.stride, c.pp) > 0 && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; break; }
+                    }
+                }
                 // 1x1 layers: the persistent pointwise kernel (same operands, same k order as the direct kernel)
                 if (conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW")) {
                     ConvCfg c = op.cfg;
-                    c.mt = 2; c.nt = 4; c.lds = false; c.ipw = 1; c.deep = false; c.ct = false; c.pw = true; c.pf2 = false; c.cm = 0; c.w8 = false;
+                    c.mt = 2; c.nt = 4; c.lds = false; c.ipw = 1; c.deep = false; c.ct = false; c.pw = true; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                     TRY(time_cfg(c));
                     if (getenv("IRMV_FORCE_PW") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                 }
@@ -1410,7 +1446,7 @@ static int autotune_convs(irmv_engine *e)
                         for (int nt = 1; nt <= 4; nt *= 2) {
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = nt; c.lds = false; c.ipw = 1; c.deep = false; c.ct = true; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false;
+                            c.mt = mt; c.nt = nt; c.lds = false; c.ipw = 1; c.deep = false; c.ct = true; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                             TRY(time_cfg(c));
                         }
                 // single-frame steps: the latency variants of the direct kernel (deep prefetch ring), same rule.
@@ -1421,7 +1457,7 @@ static int autotune_convs(irmv_engine *e)
                     for (auto &t : tiles) {
                         if (op.cout_pad % (16 * t[1]) != 0) continue;
                         ConvCfg c = op.cfg;
-                        c.mt = t[0]; c.nt = t[1]; c.lds = false; c.ipw = 1; c.deep = true; c.ct = lds_ok; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false;
+                        c.mt = t[0]; c.nt = t[1]; c.lds = false; c.ipw = 1; c.deep = true; c.ct = lds_ok; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                         TRY(time_cfg(c));
                     }
                 }

@@ -182,6 +182,8 @@ struct ConvCfg {
     bool pf2;    // LDS family, mt = 1: global -> register staging two (image, chunk) steps ahead instead of one
     bool w8;     // LDS family, stride 2: one 8-wave workgroup on a block twice as tall (weights staged for twice the pixels, mt = 2 fits LDS)
     int cm;      // LDS family: chunk-major order over the workgroup's cm = ipw images (0: image-major), weights staged once per chunk
+    bool wr;     // LDS family, Cin = Cout = 64, stride 1: the layer's weights stay resident in the LDS of one 8-wave workgroup that walks ipw images
+    bool pp;     // ... as two ping-pong groups of four waves (one in its MFMA phase while the other stores, stages and loads)
 };
 // returns false if no instantiation exists for cfg
 bool launch_conv(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
@@ -195,6 +197,10 @@ bool launch_conv_direct_multi(const ConvCfg &cfg, const ConvArgs *a, int n, hipS
 bool launch_conv_pw(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
 // LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt
 size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max, bool w8 = false);
+// weights-resident variant: bytes of LDS (0 = not eligible), tile positions per image and workgroup column, launcher
+size_t conv_wres_bytes(const ConvArgs &a, int stride, bool pp);
+int conv_wres_tiles(const ConvArgs &a, int stride, bool pp);
+bool launch_conv_wres(int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pp);
 bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2 = false, int cm = 0, bool w8 = false);   // a.n2 > 0: fused 1x1 (needs stride 1, nt 4, cout 64); pf2: staging two steps ahead (mt = 1)
 
 // SPPF pooling chain: slice 0 (C ch) of [B][H][W][4C] -> slices 1..3 (5x5, 9x9, 13x13 max)

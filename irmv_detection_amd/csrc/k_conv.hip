@@ -582,7 +582,7 @@ bool launch_conv_pw(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
 
 // 16-byte patch pieces a thread stages per chunk (registers are reserved for all of them): a stride-1 2-D block is at
 // most (16 MT + 2) x 18 pixels, the other schemes stage full-width rows or stride-2 patches.
-constexpr int lds_pmax(int stride, int mt, bool tile2d) { return (tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12; }
+constexpr int lds_pmax(int stride, int mt, bool tile2d, int wr = 0) { return wr ? 4 : ((tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12); }
 
 #ifndef IRMV_ABL
 #define IRMV_ABL 0   // timing ablations of conv3x3_lds_kernel (scripts/probes/conv_probe.cpp); results are wrong with any bit set:
@@ -593,6 +593,9 @@ constexpr int lds_pmax(int stride, int mt, bool tile2d) { return (tile2d && stri
 #if IRMV_EXP & 4
 __device__ unsigned long long g_phase[16];
 #endif
+#if IRMV_EXP & 32
+__device__ unsigned long long g_pp[2][8];   // ping-pong groups: cycles of wave 0 of each group per phase, summed over workgroups
+#endif
 #if IRMV_EXP & 2
 __device__ int g_cu_arrivals[4096];
 __device__ int g_stagger_sleeps = 0;
@@ -602,13 +605,21 @@ __device__ int g_stagger_sleeps = 0;
 #endif
 // The kernel's body as a device function of (workgroup index, grid size), so that one launch can serve several layers
 // (conv3x3_lds_multi below); conv3x3_lds_kernel itself is the thin wrapper behind it.
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
 __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch,
                                                  int wg_x, int wg_y, int grid_x, int grid_y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
     constexpr int NTH = 64 * NWV;   // NWV waves stacked along pixels (4; 8 for the stride-2 layers' large block, see launch_conv_lds)
+    // PP (ping-pong, with WR): the workgroup's waves form TWO groups of NWP = NWV / 2 waves.  Each group owns a pixel tile
+    // and a patch buffer of its own; they share the resident weights and run half a step apart -- while one group is in
+    // its MFMA phase the other runs its epilogue, writes its next patch to LDS and issues the loads of the one after --
+    // so that every SIMD always holds one wave that feeds the matrix pipe and one that feeds the vector / memory pipes.
+    static_assert(!PP || (WR > 0 && NWV % 2 == 0), "ping-pong groups share resident weights");
+    constexpr int NWP = PP ? NWV / 2 : NWV;   // waves that share one patch
+    constexpr int NTP = 64 * NWP;
+    const int sub = PP ? wave / NWP : 0, wv = wave - sub * NWP, tidp = tid - sub * NTP;
     const int g = lane >> 4, r = lane & 15;
     // Pixel ownership, two schemes:
     //  TILE2D  : a 2-D block.  An MFMA tile is (16 / TWc) rows x TWc columns, a wave stacks MT of them
@@ -627,7 +638,11 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         by = rem / tiles;
         bx = g_ * tiles + (rem - by * tiles);
     }
-    const int grp = bx / (tiles_x * tiles_y), tile = bx - grp * (tiles_x * tiles_y);
+    const int wg_tiles = PP ? (tiles_x * tiles_y + 1) / 2 : tiles_x * tiles_y;   // tile positions per workgroup column
+    const int grp = bx / wg_tiles;
+    int tile = PP ? 2 * (bx - grp * wg_tiles) + sub : bx - grp * wg_tiles;
+    const bool active = tile < tiles_x * tiles_y;       // (PP, odd tile count: the last workgroup's second group only keeps the barriers' count)
+    if (!active) tile = 0;
     const int img = grp * ipw, nimg = min(ipw, batch - img);
     const int nblk = by;
     const int HWo = a.Hout * a.Wout;
@@ -636,41 +651,47 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     bool mv[MT];
     if constexpr (TILE2D) {
         const int TWc = 1 << twc_log2, trows = 16 >> twc_log2;
-        const int RH = NWV * MT * trows;
+        const int RH = NWP * MT * trows;
         const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
         const int y0 = tyi * RH, x0 = txi * TWc;
         PW = TWc * STRIDE + 2; PR = RH * STRIDE + 2;
         iy_base = y0 * STRIDE - 1; ix_base = x0 * STRIDE - 1;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const int ly = (wave * MT + mt) * trows + (r >> twc_log2), lx = r & (TWc - 1);
+            const int ly = (wv * MT + mt) * trows + (r >> twc_log2), lx = r & (TWc - 1);
             const int oy = y0 + ly, ox = x0 + lx;
-            mv[mt] = oy < a.Hout && ox < a.Wout;
+            mv[mt] = active && oy < a.Hout && ox < a.Wout;
             mloc[mt] = mv[mt] ? oy * a.Wout + ox : 0;
             poff[mt] = ((ly * STRIDE) * PW + lx * STRIDE) * pix_stride(STRIDE) + g * 16;
         }
     } else {
-        constexpr int TPX = 16 * NWV * MT;
+        constexpr int TPX = 16 * NWP * MT;
         const int m0 = tile * TPX, m1 = min(m0 + TPX, HWo);
         const int y0 = m0 / a.Wout, y1 = (m1 - 1) / a.Wout;
         PW = a.Win + 2; PR = (y1 - y0) * STRIDE + 3;
         iy_base = y0 * STRIDE - 1; ix_base = -1;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const int m = m0 + (wave * MT + mt) * 16 + r;
-            mv[mt] = m < m1;
+            const int m = m0 + (wv * MT + mt) * 16 + r;
+            mv[mt] = active && m < m1;
             mloc[mt] = mv[mt] ? m : m0;
             const int oy = mloc[mt] / a.Wout, ox = mloc[mt] - oy * a.Wout;
             poff[mt] = (((oy - y0) * STRIDE) * PW + ox * STRIDE) * pix_stride(STRIDE) + g * 16;
         }
     }
-    unsigned char *s_patch = smem;
-    half8 *s_w = reinterpret_cast<half8 *>(smem + (size_t)a_patch_bytes);
+    // WR > 0 (weights resident): the layer has exactly WR chunks; the weights of ALL of them are staged once per workgroup
+    // and stay, the patch holds all WR chunk planes of an image, and a step is a whole image (one pair of barriers per
+    // image instead of one per chunk, no weight traffic after the first step) -- see launch_conv_wres.
+    constexpr int NPL = WR > 0 ? WR : 1;               // chunk planes of the patch / chunk slabs of the weights in LDS
+    static_assert(WR == 0 || (!PF2 && CM == 0), "resident weights: image-major steps, one step of staging lead");
+    constexpr int NPB = PP ? 2 * NPL : NPL;            // patch planes in LDS (one set per ping-pong group)
+    unsigned char *s_patch = smem + (size_t)sub * NPL * a_patch_bytes;
+    half8 *s_w = reinterpret_cast<half8 *>(smem + (size_t)NPB * a_patch_bytes);
     // epilogue constants, staged once: bias of this workgroup's 16 NT channels, then (N2 > 0) the fused 1x1's bias and its
     // A fragments.  Read from global memory inside the epilogue they cost a memory round trip per 16 x 32 output block:
     // a load after a store has to wait for the store (the compiler cannot prove bias and output apart), and every wait on
     // a load also waits for the staging loads in flight ahead of it.
-    float *s_bias = reinterpret_cast<float *>(smem + (size_t)a_patch_bytes + 9 * NT * 1024);
+    float *s_bias = reinterpret_cast<float *>(smem + (size_t)NPB * a_patch_bytes + (size_t)NPL * 9 * NT * 1024);
     float *s_bias2 = s_bias + 64;
     half8 *s_w2 = reinterpret_cast<half8 *>(s_bias + 128);
     if constexpr (NT % 2 == 0) {
@@ -687,7 +708,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 
     // staging plan: element e -> (patch pixel, 16-byte quarter); weights: 9*NT*64 half8 per chunk
-    constexpr int PMAX = lds_pmax(STRIDE, MT, TILE2D);   // patch 16-B pieces per thread (host guarantees the fit)
+    constexpr int PMAX = lds_pmax(STRIDE, MT, TILE2D, WR);   // patch 16-B pieces per thread and chunk plane (host guarantees the fit)
     constexpr int WPT = (9 * NT * 64 + NTH - 1) / NTH; // weight half8 per thread
     const int n_pe = PR * PW * 4;
     const float inv_pw = 1.0f / (float)PW;
@@ -696,19 +717,19 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     bool val_p[PMAX], use_p[PMAX];
 #pragma unroll
     for (int i = 0; i < PMAX; i++) {
-        const int e = tid + i * NTH;
+        const int e = tidp + i * NTP;
         use_p[i] = e < n_pe;
         val_p[i] = false;
         src_p[i] = a.s0.p;
         dst_p[i] = 0;
-        if (i * NTH >= n_pe) continue;                     // wave-uniform: this piece slot is unused by the whole workgroup
+        if (i * NTP >= n_pe) continue;                     // wave-uniform: this piece slot is unused by the whole workgroup
         const int pix = use_p[i] ? (e >> 2) : 0, q = e & 3;
         int pr = (int)((float)pix * inv_pw);               // pix < 2^16: one correction step makes the quotient exact
         pr -= (pr * PW > pix) ? 1 : 0;
         pr += ((pr + 1) * PW <= pix) ? 1 : 0;
         const int pc = pix - pr * PW;
         const int iy = iy_base + pr, ix = ix_base + pc;
-        val_p[i] = use_p[i] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        val_p[i] = active && use_p[i] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
         src_p[i] = a.s0.p + ((size_t)(img * a.Hin + (val_p[i] ? iy : 0)) * a.Win + (val_p[i] ? ix : 0)) * a.s0.ld + q * 8;
         dst_p[i] = pix * pix_stride(STRIDE) + q * 16;
     }
@@ -908,9 +929,11 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     // after the barrier they fill the CU's vector-memory queue (17 wave-instructions of 1 KiB against 64 B/clk) and the
     // wave sits in the issue stall instead of starting its MFMAs.  The last step re-loads its own pieces (no branch).
     constexpr int NPIECE = PMAX + WPT, PER_TAP = (NPIECE + 8) / 9;
-    auto taps = [&](auto spread, auto ai_) {
+    auto taps = [&](auto spread, auto ai_, int plane = 0) {
         constexpr bool SPREAD = decltype(spread)::value;
         auto &accx = acc[decltype(ai_)::value];
+        const unsigned char *s_pl = s_patch + (size_t)plane * a_patch_bytes;   // (WR: chunk plane of the patch, chunk slab of the weights)
+        const half8 *s_wc = s_w + plane * (9 * NT * 64);
         size_t off = 0;
         if constexpr (SPREAD) {
             if (l_im == nimg) { l_im = nimg - 1; l_chunk = chunks - 1; }
@@ -935,9 +958,9 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
             const int toff = (kh * PW + kw) * pix_stride(STRIDE);
             half8 A[NT], B[MT];
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) A[nt] = s_w[(tap * NT + nt) * 64 + lane];
+            for (int nt = 0; nt < NT; nt++) A[nt] = s_wc[(tap * NT + nt) * 64 + lane];
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) B[mt] = *reinterpret_cast<const half8 *>(s_patch + poff[mt] + toff);
+            for (int mt = 0; mt < MT; mt++) B[mt] = *reinterpret_cast<const half8 *>(s_pl + poff[mt] + toff);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -948,6 +971,47 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         if constexpr (SPREAD) {
             if (++l_chunk == chunks) { l_chunk = 0; l_im++; }
         }
+    };
+    // WR: all WR * 9 k-steps of an image as ONE software-pipelined sequence -- the fragments of k-step s + 1 are requested
+    // from LDS before the MFMAs of k-step s are issued (the scheduling barrier pins that order: left to itself the
+    // compiler reads a fragment right in front of its first use and the wave -- in ping-pong mode the only one on its SIMD
+    // that feeds the matrix pipe -- sits out the LDS latency 18 times per image).
+    auto ksteps_wr = [&]() {
+        constexpr int KS = (WR > 0 ? WR : 1) * 9;
+        auto &accx = acc[0];
+        half8 A[2][NT], B[2][MT];
+        auto frag = [&](auto ks_, half8 (&Af)[NT], half8 (&Bf)[MT]) {
+            constexpr int ks = decltype(ks_)::value, c = ks / 9, tap = ks % 9, kh = tap / 3, kw = tap % 3;
+            const unsigned char *s_pl = s_patch + (size_t)c * a_patch_bytes + (kh * PW + kw) * pix_stride(STRIDE);
+            const half8 *s_wc = s_w + (c * 9 + tap) * (NT * 64) + lane;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) Af[nt] = s_wc[nt * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) Bf[mt] = *reinterpret_cast<const half8 *>(s_pl + poff[mt]);
+        };
+        frag(std::integral_constant<int, 0>{}, A[0], B[0]);
+        auto step = [&](auto ks_) {
+            constexpr int ks = decltype(ks_)::value;
+            if constexpr (ks + 1 < KS) frag(std::integral_constant<int, ks + 1>{}, A[(ks + 1) & 1], B[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    if (!(IRMV_ABL & 4)) accx[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks & 1][nt], B[ks & 1][mt], accx[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto run = [&](auto self, auto ks_) -> void {
+            constexpr int ks = decltype(ks_)::value;
+            if constexpr (ks < KS) { step(ks_); self(self, std::integral_constant<int, ks + 1>{}); }
+        };
+#if IRMV_EXP & 16
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        run(run, std::integral_constant<int, 0>{});
+#if IRMV_EXP & 16
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     auto mma_step = [&]() {
         taps(std::false_type{}, I0{});
@@ -1023,7 +1087,91 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         return;
     }
 #endif
-    if constexpr (CM > 0) {
+    if constexpr (WR > 0) {
+        // ---- weights resident: stage all WR chunk slabs once, then one step per image ----
+        {
+            constexpr int WALL = WR * 9 * NT * 64, WPA = (WALL + NTH - 1) / NTH;   // half8 pieces, per thread
+            half8 wr_[WPA];
+#pragma unroll
+            for (int i = 0; i < WPA; i++) {
+                const int e = tid + i * NTH;
+                wr_[i] = wsrc[e < WALL ? e : WALL - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < WPA; i++) {
+                const int e = tid + i * NTH;
+                if (e < WALL) s_w[e] = wr_[i];
+            }
+        }
+        half8 rq[WR][PMAX];
+        auto issue_wr = [&](int im) {
+            const size_t off = (size_t)im * img_stride;
+#pragma unroll
+            for (int c = 0; c < WR; c++)
+#pragma unroll
+                for (int i = 0; i < PMAX; i++) {
+                    rq[c][i] = zero8;
+                    if (val_p[i]) rq[c][i] = *reinterpret_cast<const half8 *>(src_p[i] + off + c * 32);
+                }
+        };
+        auto write_wr = [&]() {
+#pragma unroll
+            for (int c = 0; c < WR; c++)
+#pragma unroll
+                for (int i = 0; i < PMAX; i++)
+                    if (use_p[i]) *reinterpret_cast<half8 *>(s_patch + (size_t)c * a_patch_bytes + dst_p[i]) = rq[c][i];
+        };
+        if constexpr (PP) {
+            // group 1 runs one barrier (= half a step) behind group 0; both execute 2 nimg + 2 barriers
+            issue_wr(0);
+            if (sub == 1) __builtin_amdgcn_s_barrier();
+            write_wr();
+            if (nimg > 1) issue_wr(1);
+            __syncthreads();
+#if IRMV_EXP & 32
+            long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            long long t_prev = clock64();
+            const long long t_begin = t_prev;
+            auto stamp = [&](int k) { const long long t = clock64(); t_acc[k] += t - t_prev; t_prev = t; };
+#else
+            auto stamp = [&](int) {};
+#endif
+            for (int s = 0; s < nimg; s++) {
+                ksteps_wr();                                                          // MFMA phase (the other group: load phase)
+                stamp(0);
+                __syncthreads();
+                stamp(1);
+                store_tile(img + s, I0{});                                            // load phase (the other group: MFMA phase)
+                stamp(2);
+                if (s + 1 < nimg) {
+                    if (!(IRMV_ABL & 2)) write_wr();
+                    stamp(3);
+                    if (s + 2 < nimg && !(IRMV_ABL & 2)) issue_wr(s + 2);
+                    stamp(4);
+                }
+                __syncthreads();
+                stamp(5);
+            }
+            if (sub == 0) __builtin_amdgcn_s_barrier();
+#if IRMV_EXP & 32
+            if (tidp == 0) {
+                for (int k = 0; k < 6; k++) atomicAdd(&g_pp[sub][k], (unsigned long long)t_acc[k]);
+                atomicAdd(&g_pp[sub][6], (unsigned long long)(clock64() - t_begin));
+                atomicAdd(&g_pp[sub][7], (unsigned long long)nimg);
+            }
+#endif
+            return;
+        }
+        issue_wr(0);
+        for (int s = 0; s < nimg; s++) {
+            if (!(IRMV_ABL & 2) || s == 0) write_wr();
+            __syncthreads();
+            if (s + 1 < nimg && !(IRMV_ABL & 2)) issue_wr(s + 1);
+            ksteps_wr();
+            __syncthreads();
+            store_tile(img + s, I0{});
+        }
+    } else if constexpr (CM > 0) {
         static_assert(!PF2 && CM <= 4, "chunk-major order: one step of staging lead, at most four images");
         auto each_image = [&](auto f) {
             f(std::integral_constant<int, 0>{});
@@ -1084,10 +1232,10 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     }
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
 {
-    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // Several independent 3x3 layers in ONE launch (the Detect branches of the three levels in a single-frame step: fifteen
@@ -1115,8 +1263,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
 // block tiles the image exactly (no masked lanes); otherwise the row-run scheme.  bytes == 0: not eligible.
 struct LdsGeom { bool tile2d; int tiles_x, tiles_y, twc_log2, patch_bytes; size_t bytes; };
 
-static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt, int nwv = 4)
-{
+static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt, int nwv = 4, int wr = 0, bool pp = false)
+{   // nwv: the waves that share one patch (ping-pong: half the workgroup's)
     LdsGeom g{false, 0, 0, 0, 0, 0};
     if (a.Cin % 32 != 0 || a.s1.C != 0 || a.s0.shift != 0) return g;
     if (!((nt == 1) || ((nt == 2 || nt == 4) && a.pair))) return g;
@@ -1139,10 +1287,11 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt, int nwv =
         pr = (rows - 1) * stride + 3;
         pw = a.Win + 2;
     }
-    if ((size_t)pr * pw * 4 > (size_t)lds_pmax(stride, mt, g.tile2d) * 64 * nwv) return g;   // staging plan: pieces per thread
+    if ((size_t)pr * pw * 4 > (size_t)lds_pmax(stride, mt, g.tile2d, wr) * 64 * nwv) return g;   // staging plan: pieces per thread
     g.patch_bytes = pr * pw * pix_stride(stride);
-    const size_t bytes = (size_t)g.patch_bytes + (size_t)9 * nt * 1024 + 512 + (size_t)a.n2 * 2048;   // + bias, bias2, fused 1x1 fragments
-    if (bytes > (size_t)(nwv == 8 ? 150 : 80) * 1024) return g;   // two or more 4-wave workgroups per CU, or one of 8 waves
+    const int planes = wr ? wr : 1;                     // resident weights: every chunk's patch plane and weight slab at once
+    const size_t bytes = (size_t)planes * (pp ? 2 : 1) * g.patch_bytes + (size_t)planes * 9 * nt * 1024 + 512 + (size_t)a.n2 * 2048;   // + bias, bias2, fused 1x1 fragments
+    if (bytes > (size_t)(wr ? 160 : (nwv == 8 ? 150 : 80)) * 1024) return g;   // two or more 4-wave workgroups per CU, or one of 8 waves
     g.bytes = bytes;
     return g;
 }
@@ -1154,16 +1303,61 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
     return g.bytes;
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
 static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int ipw, const LdsGeom &g, hipStream_t s)
 {
     static unsigned long long attr_done = 0;   // per instantiation: devices whose dynamic-LDS limit has been raised
     once_per_device(attr_done, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int groups = (batch + ipw - 1) / ipw;
-    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV>), dim3(g.tiles_x * g.tiles_y * groups, a.cout_pad / (16 * NT)), dim3(64 * NWV), g.bytes, s, a,
+    const int wg_tiles = PP ? (g.tiles_x * g.tiles_y + 1) / 2 : g.tiles_x * g.tiles_y;   // ping-pong: two tile positions per workgroup
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>), dim3(wg_tiles * groups, a.cout_pad / (16 * NT)), dim3(64 * NWV), g.bytes, s, a,
                        wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch);
+}
+
+// Weights-resident variant: Cin = 64 -> 64 channels, stride 1.  ONE 8-wave workgroup per CU keeps the
+// layer's whole 72 KiB of weights in LDS and walks `ipw` images at its tile position (any ipw >= 1: the grid is sized so
+// that the chip holds it in one round); per image it stages the 64-channel patch once and runs all 18 k-steps between
+// one pair of barriers.  Same K order as the chunked kernel (chunk, tap) -> bit-identical.
+static LdsGeom wres_geom(const ConvArgs &a, int stride, bool pp)
+{
+    if (stride != 1 || a.Cin != 64 || a.cout_pad != 64 || !a.pair || (a.n2 > 0 && a.res) || a.xcd || !(a.n2 == 0 || a.n2 == 1 || a.n2 == 4)) return LdsGeom{false, 0, 0, 0, 0, 0};
+    LdsGeom g = pp ? lds_geom(a, 1, 2, 4, 4, 2, true) : lds_geom(a, 1, 2, 4, 8, 2);
+    if (pp && !g.tile2d) g.bytes = 0;   // ping-pong groups: 2-D blocks only
+    return g;
+}
+size_t conv_wres_bytes(const ConvArgs &a, int stride, bool pp) { return wres_geom(a, stride, pp).bytes; }
+int conv_wres_tiles(const ConvArgs &a, int stride, bool pp)
+{
+    const LdsGeom g = wres_geom(a, stride, pp);
+    if (!g.bytes) return 0;
+    return pp ? (g.tiles_x * g.tiles_y + 1) / 2 : g.tiles_x * g.tiles_y;
+}
+
+bool launch_conv_wres(int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pp)
+{
+    if (ipw < 1) ipw = 1;
+    if (pp) {   // ping-pong: two groups of four waves, each on its own (4 mt rows x 16)-pixel block
+        const LdsGeom gp = wres_geom(a, 1, true);
+        if (!gp.bytes) return false;
+#define IRMV_WRES_PP(N2_)                                                                                   \
+        if (a.n2 == N2_) { launch_lds_inst<1, 2, 4, true, N2_, false, 0, 8, 2, true>(a, wl, batch, ipw, gp, s); return true; }
+        IRMV_WRES_PP(0) IRMV_WRES_PP(1) IRMV_WRES_PP(4)
+#undef IRMV_WRES_PP
+        return false;
+    }
+    const LdsGeom g = wres_geom(a, 1, false);
+    if (!g.bytes) return false;
+#define IRMV_WRES(N2_)                                                                                      \
+    if (a.n2 == N2_) {                                                                                      \
+        if (g.tile2d) launch_lds_inst<1, 2, 4, true, N2_, false, 0, 8, 2>(a, wl, batch, ipw, g, s);          \
+        else launch_lds_inst<1, 2, 4, false, N2_, false, 0, 8, 2>(a, wl, batch, ipw, g, s);                  \
+        return true;                                                                                        \
+    }
+    IRMV_WRES(0) IRMV_WRES(1) IRMV_WRES(4)
+#undef IRMV_WRES
+    return false;
 }
 
 bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2, int cm, bool w8)

@@ -457,6 +457,41 @@ def test_chunk_major_and_eight_wave_tiles_are_bitwise_the_plain_ones(blob, monke
             assert np.array_equal(v, heads["IRMV_NO_CM_taps"][k]), (mode, k)
 
 
+@pytest.mark.parametrize("net", [640, 416])
+def test_resident_weight_kernels_are_bitwise_the_chunked_ones(blob, monkeypatch, net):
+    """The Cin = Cout = 64 3x3 layers on the weights-resident kernel (k_conv.hip WR: all 18 k-steps of an image between one
+    pair of barriers, the layer's 72 KiB of weights staged once per workgroup) -- as two ping-pong groups of four waves
+    where the map tiles into 8 x 16 blocks (80 x 80), in lockstep on row runs elsewhere (40 x 40, 20 x 20; 52 / 26 / 13 at a
+    416 net) -- against the chunked 4-wave kernels: same K order (chunk, tap) -> same bits.  Seven frames, three per
+    workgroup: two full image groups and a short one; the fused Detect finals (N2 = 1 with candidate emission, N2 = 4) and
+    the C2f shortcut convs ride along."""
+    imgs = [frames.synthetic_frame(90 + i) for i in range(7)]
+    out = {}
+    for mode, val in (("IRMV_FORCE_WRES", "3"), ("IRMV_FORCE_WRES", "-3"), ("IRMV_NO_WRES", "1")):
+        for m in ("IRMV_FORCE_WRES", "IRMV_NO_WRES"):
+            monkeypatch.delenv(m, raising=False)
+        monkeypatch.setenv(mode, val)
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=7, num_streams=1, net_size=net) as e:
+            names = [st["name"] for st in e.profile(0, 7)]
+            n_wr, n_pp = sum("_wres" in n for n in names), sum("_wres_pp" in n for n in names)
+            if mode == "IRMV_NO_WRES":
+                assert n_wr == 0, names
+            elif net == 640:
+                assert n_wr >= 14 and (n_pp == 4) == (val == "3"), names   # ping-pong: the four 80 x 80 Detect convs
+            else:
+                assert n_wr >= 8 and n_pp == 0, names
+            for s, im in enumerate(imgs):
+                _load(e, s, im)
+            e.submit(0, 7); e.wait()
+            key = mode + val
+            out[key] = [e.read_head(s).copy() for s in range(7)] + [e.read_tap(t, 6).copy() for t in ("6", "12", "18")]
+            out[key + "_dets"] = [[(int(d.armor_class), d.confidence, d.bbox_xyxy) for d in e.results(s)] for s in range(7)]
+    for key in ("IRMV_FORCE_WRES3", "IRMV_FORCE_WRES-3"):
+        for a, b in zip(out[key], out["IRMV_NO_WRES1"]):
+            assert np.array_equal(a, b), key
+        assert out[key + "_dets"] == out["IRMV_NO_WRES1_dets"], key
+
+
 def test_eight_wave_tiles_on_maps_that_do_not_tile(blob, monkeypatch):
     """The stride-2 layers' 8-wave workgroup on a 416 net: 52 x 52, 26 x 26 and 13 x 13 outputs take the row-run block
     scheme (no 2-D block divides them), last blocks are partial, the batch's last image group is short (three frames)."""
