@@ -14,7 +14,8 @@ synthetic 1280x1024 camera frames (already resident in HBM) through
 preprocess -> YOLOv8n (fp16 storage, fp32 accumulate) -> decode -> NMS -> keypoints
 -> PnP and returns the detections to pinned host memory.  One process per GPU;
 frames are sharded (weak scaling, no data-path collective); the weight blob is
-generated on rank 0 and broadcast once over RCCL.  Rank 0 prints ONE JSON line.
+generated on rank 0 and broadcast once over RCCL by libirmv_comm.so (include/irmv_comm.h: no torch in
+the ranks; `IRMV_DIST_BACKEND=gloo` rehearses N ranks on one GPU through torch.distributed).  Rank 0 prints ONE JSON line.
 
 `value` (= `value_hbm_resident`) is the metric as BASELINE.json words it, frames
 resident in HBM when the clock starts.  `value_host_inclusive` is SURVEY 8(d)'s clock:
@@ -137,20 +138,29 @@ def dbg(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-class _Solo:
-    """The distributed helpers at world size 1, without importing torch: a torch HIP context in the process slows every
-    HIP call of the hand-off path (measured on the GPU box, scripts/host_probe.py: host-inclusive 13.8 k -> 7.9 k FPS at
-    16-slot upload groups, host submit time x 2.3).  torch is plumbing for N > 1 (torch.distributed over RCCL) only."""
-    @staticmethod
-    def barrier(): pass
-    @staticmethod
-    def max_over_ranks(x, dev): return float(x)
-    @staticmethod
-    def shard_frames(total, rank, world): return list(range(rank, total, world))
-    @staticmethod
-    def device_index(local_rank):
-        forced = os.environ.get("IRMV_FORCE_DEVICE")
-        return int(forced) if forced is not None else local_rank
+class _TorchRanks:
+    """Legacy / rehearsal plumbing (IRMV_DIST_BACKEND=gloo|nccl): torch.distributed.  gloo lets several ranks share ONE
+    GPU (RCCL refuses that).  With torch in the process libirmv_hip.so runs on torch's bundled ROCm 7.0 runtime
+    (DESIGN.md section 6a), so this is never the default."""
+    def __init__(self):
+        import torch
+        from irmv_detection_amd import dist as D
+        self.torch, self.D = torch, D
+        self.rank, self.local_rank, self.world = D.init()
+        self.device = D.device_index(self.local_rank)
+        torch.cuda.set_device(self.device)
+        self.dev = torch.device("cuda", self.device)
+        self._wt = None
+    def broadcast_blob(self, blob):
+        self._wt = self.D.broadcast_blob(blob, self.dev)
+        self.torch.cuda.synchronize()
+        return self._wt.data_ptr(), self._wt.numel()
+    def barrier(self): self.D.barrier()
+    def max_over_ranks(self, x): return self.D.max_over_ranks(x, self.dev)
+    def sum_over_ranks(self, x): return self.D.sum_over_ranks(x, self.dev)
+    def close(self):
+        if self.world > 1:
+            self.torch.distributed.destroy_process_group()
 
 
 def main():
@@ -160,14 +170,12 @@ def main():
     from irmv_detection_amd import arch, capi, frames as F, weights
     from irmv_detection_amd.engine import DEFAULT_CAMERA_MATRIX, DEFAULT_DIST_COEFFS, YoloEngine
 
-    solo = int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("IRMV_BENCH_TORCH")
-    if solo:
-        D, torch = _Solo, None
-        rank, local_rank, world = 0, 0, 1
-    else:
-        import torch
-        from irmv_detection_amd import dist as D
-        rank, local_rank, world = D.init()
+    # Ranks: one process per GPU.  The default plumbing is libirmv_comm.so (RCCL, no torch: irmv_detection_amd/comm.py), so
+    # that N > 1 ranks run the same torch-free hand-off as N = 1; at N = 1 nothing is loaded and every call is the identity.
+    from irmv_detection_amd import comm as irmv_comm
+    backend = os.environ.get("IRMV_DIST_BACKEND", "rccl")
+    R = _TorchRanks() if backend in ("gloo", "nccl") else irmv_comm.Comm()
+    rank, local_rank, world = R.rank, R.local_rank, R.world
     # Tile choices: seed the autotuner from the table measured for this build (profiles/r01_tune_cache.txt) so that every
     # run and every rank replays the same, bitwise-neutral choices; layers missing from it are tuned on the spot.  Each
     # rank works on its own copy (the engine rewrites the file it is given).
@@ -186,35 +194,25 @@ def main():
     ndev = capi.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    dev_idx = D.device_index(local_rank)
-    if torch is not None:
-        torch.cuda.set_device(dev_idx)
-        dev = torch.device("cuda", dev_idx)
-    else:
-        dev = None
+    dev_idx = R.device
 
     def device_sync():
-        """hipDeviceSynchronize on this rank's GPU: torch.cuda.synchronize() where torch is in the process (N > 1), the same
-        call through the C ABI otherwise."""
-        if torch is not None:
-            torch.cuda.synchronize()
-        else:
-            capi.device_synchronize(dev_idx)
+        """hipDeviceSynchronize on this rank's GPU, through the C ABI."""
+        capi.device_synchronize(dev_idx)
     sw, sh = (int(v) for v in args.src.lower().split("x"))
     B = args.frames_per_step
 
     # weights: rank 0 generates, everyone receives by ONE broadcast (RCCL over xGMI)
     blob = make_blob(args) if rank == 0 else None
     backbone = arch.BACKBONE_SHUFFLE if args.model == "shufflenet" else arch.BACKBONE_C2F
-    if torch is not None:
-        wt = D.broadcast_blob(blob, dev)
-        torch.cuda.synchronize()
-        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=B, net_size=args.net)
+    if world > 1:
+        w_ptr, w_bytes = R.broadcast_blob(blob)       # device buffer owned by the communicator, alive until R.close()
+        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=w_ptr, weights_bytes=w_bytes, num_slots=B, net_size=args.net)
     else:
         eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=B, net_size=args.net)
 
     # this rank's frames: round-robin over the global frame index, made resident in HBM once
-    my = D.shard_frames(B * world, rank, world)
+    my = irmv_comm.shard_frames(B * world, rank, world)
     frames_u8 = [F.synthetic_frame(i, sw, sh) for i in my]
     for s, f in enumerate(frames_u8):
         eng.get_src_image_buffer(s)[:] = f
@@ -227,7 +225,7 @@ def main():
     eng.wait()
     dbg("timed loop")
 
-    D.barrier()
+    R.barrier()
     device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -235,8 +233,8 @@ def main():
     eng.wait()
     device_sync()
     dt = time.perf_counter() - t0
-    D.barrier()
-    dt_max = D.max_over_ranks(dt, dev)
+    R.barrier()
+    dt_max = R.max_over_ranks(dt)
     n_dets = sum(len(eng.results(s)) for s in range(B))
 
     # ---- the timed configuration, under an assertion: first and last slot of the last batched step must equal a
@@ -261,7 +259,7 @@ def main():
                 eng.submit(f, c, h2d=True, async_upload=True)
         eng.wait()
         hsteps = max(10, args.steps // 4)
-        D.barrier()
+        R.barrier()
         device_sync()
         t1 = time.perf_counter()
         for _ in range(hsteps):
@@ -270,11 +268,14 @@ def main():
         eng.wait()
         device_sync()
         dth = time.perf_counter() - t1
-        D.barrier()
-        dth = D.max_over_ranks(dth, dev)
+        R.barrier()
+        own = B * hsteps / dth                      # this GPU's own rate; every rank takes part in the three reductions
+        per_gpu = dict(min=round(-R.max_over_ranks(-own), 1), max=round(R.max_over_ranks(own), 1),
+                       mean=round((R.sum_over_ranks(own) if world > 1 else own) / world, 1))
+        dth = R.max_over_ranks(dth)
         extra["value_host_inclusive"] = round(world * B * hsteps / dth, 1)
         extra["host_inclusive"] = dict(frames_per_upload_group=G, steps=hsteps,
-                                       pcie_gbs_per_gpu=round(B * hsteps * sw * sh * 3 / dth / 1e9, 2),
+                                       pcie_gbs_per_gpu=round(B * hsteps * sw * sh * 3 / dth / 1e9, 2), per_gpu_fps=per_gpu,
                                        note="pinned host slot -> HBM on the upload stream inside the timed region, results written by the NMS "
                                             "kernel into pinned host memory; SURVEY 8(d) clock")
         extra["fps_pcie_inclusive_1gpu"] = round(B * hsteps / dth, 1)
@@ -371,10 +372,7 @@ def main():
     if rank == 0 and "latency" not in skip:
         # Latency legs on an engine shaped like the reference node's: three slots = the TripleBuffer (src/irm_detector.cpp:
         # 35-38, 68-72), a compute stream per slot.  (A second engine in the process: safe since the round-2 teardown fix.)
-        if torch is not None:
-            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=wt.data_ptr(), weights_bytes=wt.numel(), num_slots=3, net_size=args.net)
-        else:
-            leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=3, net_size=args.net)
+        leng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=3, net_size=args.net)
         for s3 in range(3):
             leng.get_src_image_buffer(s3)[:] = frames_u8[s3 % len(frames_u8)]
         # single-frame latency, host frame -> host detections (the reference's detect(), PCIe inclusive)
@@ -429,11 +427,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:      # last: nothing GPU-side is timed while the host cores are busy
             out["cpu_baseline"] = cpu_baseline(make_blob(args), frames_u8, args.cpu_frames,
                                                np.array(DEFAULT_CAMERA_MATRIX), np.array(DEFAULT_DIST_COEFFS), args.net)
-    D.barrier()
+    R.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if torch is not None and world > 1:
-        torch.distributed.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":

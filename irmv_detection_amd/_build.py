@@ -44,6 +44,25 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+COMM_PATH = os.path.join(LIB_DIR, "libirmv_comm.so")
+
+
+def build_comm(force: bool = False, verbose: bool = False) -> str:
+    """libirmv_comm.so (include/irmv_comm.h): the RCCL weight broadcast of the multi-GPU path.  Host code only; linked
+    against the ROCm installation's librccl (never torch's bundled copy)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    src = os.path.join(CSRC, "comm.cpp")
+    deps = [src, os.path.join(INCLUDE, "irmv_comm.h"), os.path.join(INCLUDE, "irmv_hip.h"), __file__]
+    if force or _stale(COMM_PATH, deps):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib")
+        cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", INCLUDE, src, "-o", COMM_PATH,
+               "-L", rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return COMM_PATH
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, "irmv_common.hpp"), os.path.join(CSRC, "pnp_device.hpp"), os.path.join(INCLUDE, "irmv_hip.h"), __file__]
@@ -68,3 +87,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force=False, verbose=True))
+    print(build_comm(force=False, verbose=True))

@@ -1,0 +1,152 @@
+"""ctypes binding of include/irmv_comm.h (libirmv_comm.so) + the launcher glue of the one-process-per-GPU form.
+
+No torch anywhere: the ranks of `bench.py --gpus N` run the same torch-free hand-off as N = 1 (a torch HIP context in
+the process puts libirmv_hip.so on torch's bundled ROCm 7.0 runtime instead of the 7.2 it was built against -- see
+DESIGN.md section 6a).  The only thing the ranks exchange outside RCCL is the 128-byte communicator id, which rank 0
+drops into a file named after the launcher's pid (single node, like the bench contract); a multi-node launcher would
+carry the same 128 bytes through its own store.
+
+Reference: single-device (test/yolo_test.cpp:16); sharding and the one broadcast are SURVEY.md section 8e.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import tempfile
+import time
+from typing import List, Optional, Tuple
+
+from . import _build
+
+ID_BYTES = 128
+_lib = None
+
+
+class CommError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        path = os.environ.get("IRMV_COMM_LIB_PATH") or _build.build_comm()
+        lib = C.CDLL(path)
+        lib.irmv_comm_last_error.restype = C.c_char_p
+        lib.irmv_comm_init_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        lib.irmv_comm_unique_id.argtypes = [C.c_char_p]
+        lib.irmv_comm_init_rank.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.irmv_comm_nranks.argtypes = [C.c_void_p]
+        lib.irmv_comm_local_ranks.argtypes = [C.c_void_p]
+        lib.irmv_comm_broadcast_blob.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        lib.irmv_comm_allreduce_f64.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        lib.irmv_comm_destroy.argtypes = [C.c_void_p]
+        lib.irmv_comm_destroy.restype = None
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise CommError(f"irmv_comm error {rc}: {load().irmv_comm_last_error().decode(errors='replace')}")
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def device_index(local_rank: int) -> int:
+    """HIP device of this rank: LOCAL_RANK, unless IRMV_FORCE_DEVICE pins every rank to one card (rehearsal)."""
+    forced = os.environ.get("IRMV_FORCE_DEVICE")
+    return int(forced) if forced is not None else local_rank
+
+
+def shard_frames(total_frames: int, rank: int, world: int) -> List[int]:
+    """Round-robin ownership: frame i -> rank i mod world."""
+    return list(range(rank, total_frames, world))
+
+
+def id_file() -> str:
+    """Where rank 0 leaves the communicator id: keyed by the launcher (parent) pid and the rendezvous port, so that two
+    launches on one node never see each other's file."""
+    return os.path.join(tempfile.gettempdir(), f"irmv_comm_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.id")
+
+
+def exchange_id(rank: int, make_id, path: Optional[str] = None, timeout_s: float = 180.0) -> bytes:
+    """Rank 0 calls make_id() and publishes the bytes (write + atomic rename); the others wait for the file."""
+    path = path or id_file()
+    if rank == 0:
+        data = make_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, path)
+        return data
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                data = f.read()
+            if len(data) == ID_BYTES:
+                return data
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise CommError(f"rank {rank}: no communicator id at {path} after {timeout_s:.0f} s")
+        time.sleep(0.02)
+
+
+class Comm:
+    """One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher).  With one rank nothing is loaded and every
+    call is the identity."""
+
+    def __init__(self):
+        self.rank, self.local_rank, self.world = env_rank_world()
+        self.device = device_index(self.local_rank)
+        self._h = C.c_void_p()
+        self._id_path = None
+        if self.world > 1:
+            L = load()
+
+            def make():
+                buf = C.create_string_buffer(ID_BYTES)
+                _check(L.irmv_comm_unique_id(buf))
+                return buf.raw
+            self._id_path = id_file()
+            uid = exchange_id(self.rank, make, self._id_path)
+            _check(L.irmv_comm_init_rank(uid, self.world, self.rank, self.device, C.byref(self._h)))
+
+    def broadcast_blob(self, blob: Optional[bytes], root: int = 0) -> Tuple[int, int]:
+        """-> (device pointer, bytes) of the blob on this rank's GPU (communicator-owned).  Only `root` passes bytes."""
+        assert self.world > 1
+        L = load()
+        ptr, n = C.c_void_p(), C.c_uint64()
+        if self.rank == root:
+            assert blob is not None
+            buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+            _check(L.irmv_comm_broadcast_blob(self._h, buf, len(blob), root, C.byref(ptr), C.byref(n)))
+        else:
+            _check(L.irmv_comm_broadcast_blob(self._h, None, 0, root, C.byref(ptr), C.byref(n)))
+        return int(ptr.value), int(n.value)
+
+    def _reduce(self, x: float, op: int) -> float:
+        if self.world == 1:
+            return float(x)
+        v = C.c_double(x)
+        _check(load().irmv_comm_allreduce_f64(self._h, C.byref(v), op))
+        return float(v.value)
+
+    def sum_over_ranks(self, x: float) -> float:
+        return self._reduce(x, 0)
+
+    def max_over_ranks(self, x: float) -> float:
+        return self._reduce(x, 1)
+
+    def barrier(self) -> None:
+        self._reduce(0.0, 0)
+
+    def close(self) -> None:
+        if self._h:
+            load().irmv_comm_destroy(self._h)
+            self._h = C.c_void_p()
+        if self.rank == 0 and self._id_path and os.path.exists(self._id_path):
+            os.remove(self._id_path)

@@ -51,7 +51,20 @@ static int fail(int code, const std::string &msg)
     } while (0)
 
 extern "C" const char *irmv_last_error(void) { return g_err.c_str(); }
-extern "C" const char *irmv_version(void) { return "irmv_hip 0.1 (gfx950)"; }
+// "irmv_hip 0.3 (gfx950; HIP runtime <hipRuntimeGetVersion>)": the runtime that actually serves this library.  It is the
+// process's FIRST libamdhip64.so.7 -- /opt/rocm's 7.2 on its own, torch's bundled 7.0 (same SONAME) when `import torch`
+// came first.
+extern "C" const char *irmv_version(void)
+{
+    static char buf[96];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int v = 0;
+        if (hipRuntimeGetVersion(&v) != hipSuccess) v = 0;
+        snprintf(buf, sizeof buf, "irmv_hip 0.3 (gfx950; HIP runtime %d)", v);
+    });
+    return buf;
+}
 extern "C" int irmv_device_synchronize(int device)
 {
     HIP_TRY(hipSetDevice(device));
