@@ -161,7 +161,9 @@ struct Op {
     half_t *w_packed = nullptr;
     half_t *w_lds[3] = {nullptr, nullptr, nullptr};   // LDS-kernel layout for nt = 1 / 2 / 4 (eligible 3x3 layers only)
     float *bias = nullptr;
-    double flops = 0, bytes = 0;  // per frame
+    double flops = 0, bytes = 0;  // per frame (bytes: activations in + out, plus the weights)
+    double w_bytes = 0;           // the weights' share of `bytes`: read once per LAUNCH, not once per frame (irmv_engine_profile)
+    double out_bytes = 0;         // the output's share (a conv that carries a fused 1x1 writes that layer's output instead of its own)
     bool pair = false;
     int lane = 0;      // 0 = main stream; 1..3 = Detect branch (box / cls / kpt) side streams in the captured graph
     int level = -1;    // Detect level of a head op: it may start as soon as P(level) exists
@@ -456,6 +458,8 @@ static int add_conv(irmv_engine *e, const std::string &layer, SegRef s0, SegRef 
     // image), the output once, the weights once
     op.bytes = 2.0 * ((double)(Hin >> s0.shift) * (Win >> s0.shift) * s0.C + (double)(Hin >> s1.shift) * (Win >> s1.shift) * s1.C) +
                (double)op.Hout * op.Wout * l->cout * (ot.f32 ? 4.0 : 2.0) + 2.0 * l->cout * l->cin * l->k * l->k;
+    op.w_bytes = 2.0 * l->cout * l->cin * l->k * l->k;
+    op.out_bytes = (double)op.Hout * op.Wout * l->cout * (ot.f32 ? 4.0 : 2.0);
     int rc = pack_conv(e, *l, op);
     if (rc) return rc;
     e->ops.push_back(op);
@@ -567,7 +571,7 @@ static int fuse_c2f32(irmv_engine *e, const std::string &prefix, int n, bool sho
     }
     if (!ok) return IRMV_OK;
     const int bH = c1.Hin, bW = c1.Win;          // (copies: the pushes below may move e->ops)
-    const double c1_bytes = c1.bytes;
+    const double c1_bytes = c1.bytes, c1_w = c1.w_bytes;
     auto make = [&](int mode, int i_cv1, int i_m1, int i_m2, int i_cv2, const char *nm) {
         Op op;
         op.kind = OP_C2F32;
@@ -581,9 +585,10 @@ static int fuse_c2f32(irmv_engine *e, const std::string &prefix, int n, bool sho
         op.res_t = cat;                              // the block's concat buffer
         const double px = (double)bH * bW;
         for (int k = 0; k < 4; k++)
-            if (op.sub[k] >= 0) { op.flops += e->ops[op.sub[k]].flops; e->ops[op.sub[k]].fused_away = true; }
-        // algorithmic bytes: block input once (mode 0 / 1), concat slices written / read, block output, weights
-        if (mode != 2) op.bytes += c1_bytes - px * 64 * 2.0;                       // cv1's inputs + weights
+            if (op.sub[k] >= 0) { op.flops += e->ops[op.sub[k]].flops; e->ops[op.sub[k]].fused_away = true; op.w_bytes += e->ops[op.sub[k]].w_bytes; }
+        // algorithmic bytes: block input once (mode 0 / 1), concat slices written / read, block output, every fused layer's weights
+        op.bytes = op.w_bytes;
+        if (mode != 2) op.bytes += c1_bytes - c1_w - px * 64 * 2.0;                // cv1's inputs
         if (mode == 1) op.bytes += px * 96 * 2.0;                                   // y0 | y1 | y2 written
         if (mode == 2) op.bytes += px * 96 * 2.0;                                   // read back
         if (mode != 1) op.bytes += px * 64 * 2.0;                                   // block output
@@ -2391,7 +2396,13 @@ extern "C" int irmv_engine_profile(irmv_engine *e, int first, int count, irmv_ke
             snprintf(st.name, sizeof st.name, "%s", (count == 1 && stream_share(e, e->cfg.num_slots) > 1 && op.kind == OP_CONV) ? op.kname_one : op.kname);
             snprintf(st.layer, sizeof st.layer, "%s", op.layer.c_str());
             st.flops = (op.flops + (op.fuse_next >= 0 ? e->ops[op.fuse_next].flops : 0.0)) * count;
-            st.bytes = op.bytes * count;
+            double b = op.bytes, w = op.w_bytes;
+            if (op.fuse_next >= 0) {   // the fused 1x1's output is what reaches memory, its weights ride along
+                const Op &nx = e->ops[op.fuse_next];
+                b += nx.out_bytes - op.out_bytes + nx.w_bytes;
+                w += nx.w_bytes;
+            }
+            st.bytes = (b - w) * count + w;   // activations per frame, weights once per launch
             }
             st.ms = ms;
         }
