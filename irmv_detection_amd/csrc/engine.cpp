@@ -4,7 +4,8 @@
 // src/yolo_engine.cpp) and PnPSolver (src/pnp_solver.cpp):
 //   * frame slots are pinned host memory (hipHostMalloc) copied to HBM by an
 //     async copy on a dedicated upload stream, event-chained to the captured
-//     step (results come back on a download stream of their own) -- the dGPU
+//     step (results need no download: the NMS kernel stores its records straight into mapped pinned host memory;
+//     only the classical-extraction mode keeps device records + one D2H copy) -- the dGPU
 //     answer to the reference's cudaMallocManaged source buffer (:60-61) +
 //     TripleBuffer: slot n+1 uploads while slot n computes;
 //   * one set of weights per device shared by all slots (the reference builds
@@ -165,7 +166,7 @@ struct Op {
     double w_bytes = 0;           // the weights' share of `bytes`: read once per LAUNCH, not once per frame (irmv_engine_profile)
     double out_bytes = 0;         // the output's share (a conv that carries a fused 1x1 writes that layer's output instead of its own)
     bool pair = false;
-    int lane = 0;      // 0 = main stream; 1..3 = Detect branch (box / cls / kpt) side streams in the captured graph
+    int lane = 0;      // 0 = trunk; 1..3 = Detect branch (box / cls / kpt): which grouped launch a head conv may join
     int level = -1;    // Detect level of a head op: it may start as soon as P(level) exists
     int signal = -1;   // >= 0: this op produces P(signal); side lanes wait on its event
     char kname[48] = {0};
@@ -209,15 +210,11 @@ struct irmv_engine {
     int emit_level_abase[3] = {0, 0, 0};
     bool split_scan = true;   // scan + box decode as a multi-workgroup kernel in front of nms_pnp (IRMV_SPLIT_SCAN=0: inside it)
     int *cand_counts = nullptr;
-    bool xcd_order = false;   // conv kernels walk their workgroup lists XCD-contiguously (IRMV_XCD)
     int lvl_hw[3] = {0, 0, 0}, lvl_base[3] = {0, 0, 0};
     size_t frame_bytes = 0;
     hipStream_t stream = nullptr;                 // stream 0: single-slot detect(), read-backs, profile
     hipStream_t extra_streams[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // streams 1..num_streams-1
     int num_streams = 1;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // Detect-branch lanes (only ever used under stream capture)
-    hipEvent_t ev_level[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
-    bool fork_head = false;   // opt-in (IRMV_FORK_HEAD=1): measured 11 % SLOWER than the linear graph at 16 frames/step
     // frame hand-off: uploads can ride a stream of their own, chained to the compute streams by the
     // events of the submitted slot group
     hipStream_t h2d_stream = nullptr;
@@ -286,8 +283,6 @@ irmv_engine::~irmv_engine()
     if (stream) (void)hipStreamSynchronize(stream);
     for (int i = 0; i < 7; i++)
         if (extra_streams[i]) (void)hipStreamSynchronize(extra_streams[i]);
-    for (int i = 0; i < 3; i++)
-        if (side[i]) (void)hipStreamSynchronize(side[i]);
     if (h2d_stream) (void)hipStreamSynchronize(h2d_stream);
     if (dbg_dev) {   // diagnostic: phase cycles of the last nms_pnp launch per slot (100 MHz s_memtime-independent clock64)
         std::vector<long long> h((size_t)cfg.num_slots * 8);
@@ -308,11 +303,6 @@ irmv_engine::~irmv_engine()
     for (auto &kv : groups) {
         if (kv.second.h2d) (void)hipEventDestroy(kv.second.h2d);
         if (kv.second.out) (void)hipEventDestroy(kv.second.out);
-    }
-    for (int i = 0; i < 3; i++) {
-        if (ev_level[i]) (void)hipEventDestroy(ev_level[i]);
-        if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-        if (side[i]) (void)hipStreamDestroy(side[i]);
     }
     for (int i = 0; i < 7; i++)
         if (extra_streams[i]) (void)hipStreamDestroy(extra_streams[i]);
@@ -684,14 +674,6 @@ static int build_engine(irmv_engine *e)
     const int net = c.net_size, S = c.num_slots;
     HIP_TRY(hipSetDevice(c.device));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    { const char *f = getenv("IRMV_FORK_HEAD"); e->fork_head = f && f[0] == '1'; }
-    // the capture side lanes exist only for the (off by default) forked head: HIP streams are multiplexed onto a few
-    // hardware queues, and idle streams of one engine cost another engine's streams their queue
-    for (int i = 0; i < 3 && e->fork_head; i++) {
-        HIP_TRY(hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_level[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
-    }
     // default: batched engines replay concurrent sub-batches of ~64 frames, two to four of them; a stream per slot
     // for engines of TripleBuffer size, whose single-slot steps then overlap
     e->num_streams = c.num_streams > 0 ? c.num_streams : (c.num_slots <= 4 ? c.num_slots : std::min(4, std::max(2, (c.num_slots + 63) / 64)));   // batched: graphs of ~64 frames
@@ -700,7 +682,6 @@ static int build_engine(irmv_engine *e)
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->h2d_stream, hipStreamNonBlocking));
     { const char *ic = getenv("IRMV_INLINE_COPIES"); e->inline_copies = ic && ic[0] == '1'; }
-    { const char *xo = getenv("IRMV_XCD"); e->xcd_order = xo && xo[0] == '1'; }
     e->slot_owner.assign(S, nullptr);
     e->frame_bytes = (size_t)c.src_width * c.src_height * 3;
     HIP_TRY(hipHostMalloc((void **)&e->src_host, e->frame_bytes * S, hipHostMallocDefault));
@@ -889,8 +870,8 @@ static int build_engine(irmv_engine *e)
     // is staged once.  Batched engines keep the separate convs (their nt = 4 tiles do not divide 160 channels).
     {
         const char *mh = getenv("IRMV_MERGE_HEAD0");
-        e->merge_head0 = stream_share(e, S) == 1 && !e->fork_head && !(mh && mh[0] == '0');
-        if (mh && mh[0] == '1') e->merge_head0 = !e->fork_head;
+        e->merge_head0 = stream_share(e, S) == 1 && !(mh && mh[0] == '0');
+        if (mh && mh[0] == '1') e->merge_head0 = true;
         for (int i = 0; i < 3 && e->merge_head0; i++)          // every branch conv must have the shape the merge assumes
             for (int b = 0; b < nbr; b++) {
                 const LayerW *l0 = find_layer(e, std::string("model.22.") + br[b] + "." + std::to_string(i) + ".0");
@@ -945,7 +926,7 @@ static int build_engine(irmv_engine *e)
                 const int i1 = (int)e->ops.size() - 2, i2 = i1 + 1;
                 const Op &o1 = e->ops[i1], &o2 = e->ops[i2];
                 const char *fh = getenv("IRMV_FUSED_HEAD");
-                if (!(fh && fh[0] == '0') && !e->fork_head && o1.cout == 64 && o1.cin % 32 == 0 && o1.pair && o1.res_t < 0 && o1.cfg.stride == 1 &&
+                if (!(fh && fh[0] == '0') && o1.cout == 64 && o1.cin % 32 == 0 && o1.pair && o1.res_t < 0 && o1.cfg.stride == 1 &&
                     o2.cin == 64 && o2.ksteps == 2 && o2.cfg.ks == 1 && o2.cfg.out_f32 && o2.cfg.act == 0 && (o2.cout_pad == 16 || o2.cout_pad == 64))
                     e->ops[i1].fuse_next = i2;
             }
@@ -1551,7 +1532,7 @@ static bool launch_head_group(const irmv_engine *e, const irmv_engine::HeadGroup
 static int build_head_groups(irmv_engine *e)
 {
     const char *gh = getenv("IRMV_GROUP_HEAD");
-    if (!e->merge_head0 || e->fork_head || (gh && gh[0] == '0')) return IRMV_OK;
+    if (!e->merge_head0 || (gh && gh[0] == '0')) return IRMV_OK;
     auto find_op = [&](const std::string &layer) {
         for (size_t i = 0; i < e->ops.size(); i++)
             if (e->ops[i].kind == OP_CONV && !e->ops[i].fused_away && e->ops[i].layer == layer) return (int)i;
@@ -1665,7 +1646,6 @@ static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int co
         cs.shift = s.shift;
         return cs;
     };
-    a.xcd = e->xcd_order ? 1 : 0;
     a.s0 = seg(op.s0);
     a.s1 = seg(op.s1);
     a.Hin = op.Hin; a.Win = op.Win; a.Hout = op.Hout; a.Wout = op.Wout;
@@ -1748,11 +1728,8 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
     const bool capturing = (flags & 0x40000000u) != 0;
     const bool materialize = (flags & 0x20000000u) != 0;
     const PostArgs pa = post_args(e, first);
-    // Under capture the three Detect branches ride side streams: branch chains of level i depend only on
-    // P(i), so the big P3 head convs overlap the small neck / P4 / P5 layers in the replayed graph.
-    const bool fork = capturing && e->fork_head && !post_only;
-    bool lane_used[3] = {false, false, false};
-    int lane_level[3] = {-1, -1, -1};
+    (void)capturing;   // a step is one line of launches (the Detect branches forked onto side streams inside the captured graph
+                       // measured 11 % slower: DESIGN.md section 6a; the option was removed in round 3)
     for (const Op &op : e->ops) {
         if (post_only && op.kind != OP_NMS && op.kind != OP_LIGHT && op.kind != OP_SCAN) continue;
         if (op.kind == OP_SCAN && e->emit_scan && !post_only) continue;   // the class-branch convs have already filled the key lists
@@ -1762,22 +1739,6 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         // normally carries a 1x1 in its epilogue)
         if (materialize ? !(op.fused_away || op.fuse_next >= 0) : op.fused_away) continue;
         hipStream_t s = e->stream;
-        if (fork && op.lane > 0) {
-            const int ln = op.lane - 1;
-            s = e->side[ln];
-            if (lane_level[ln] != op.level) {   // first op of this level on this lane: wait for P(level)
-                HIP_TRY(hipStreamWaitEvent(s, e->ev_level[op.level], 0));
-                lane_level[ln] = op.level;
-            }
-            lane_used[ln] = true;
-        }
-        if (fork && op.kind == (e->split_scan ? OP_SCAN : OP_NMS)) {        // join the lanes before post-processing
-            for (int ln = 0; ln < 3; ln++)
-                if (lane_used[ln]) {
-                    HIP_TRY(hipEventRecord(e->ev_join[ln], e->side[ln]));
-                    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join[ln], 0));
-                }
-        }
         EvRec r{};
         r.op = (int)(&op - e->ops.data());
         if (ev) {
@@ -1911,7 +1872,6 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         case OP_LIGHT: launch_light_extract(light_args(e, first), e->cfg.max_det, count, s); break;
         }
         HIP_TRY(hipGetLastError());
-        if (fork && op.signal >= 0) HIP_TRY(hipEventRecord(e->ev_level[op.signal], e->stream));
         if (ev) {
             HIP_TRY(hipEventRecord(r.b, s));
             ev->push_back(r);

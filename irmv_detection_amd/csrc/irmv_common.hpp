@@ -146,7 +146,6 @@ struct ConvArgs {
     const float *bias2;
     float *out2;
     int out2_ld, n2;
-    int xcd;            // 1: XCD-aware workgroup order (k_conv.hip xcd_order)
     // Detect class branch only (the fused 1x1 IS the class-logit conv): candidates are thresholded where the logits are
     // computed and appended to the frame's key list -- the separate scan over the head tensor then never runs.
     unsigned long long *scan_keys;   // [B][scan_key_cap], nullptr = off

@@ -32,15 +32,8 @@ struct DeepPrefetchDepth { static constexpr int value = (MT + NT <= 2) ? 12 : ((
 
 // CT: walk K chunk-major -- k-step s = (32-channel chunk s / 9, tap s % 9), the order of the LDS-staged family below -- with
 // weights in that family's nt = 1 packing, so a 3x3 layer of the LDS family can run on this kernel bit-identically.
-// XCD-aware workgroup order (cdna_hip_programming.md T1): workgroup ids are dealt round-robin to the 8 XCDs, each with its
-// own L2.  `xcd_order` turns the id into a position in a list of which every XCD walks one CONTIGUOUS eighth -- with the
-// lists below ordered image-major, an XCD works on the same images in every layer, so a layer reads what the previous one
-// left in that XCD's L2.  Bijective for any grid size; purely a placement choice (results cannot depend on it).
-__device__ __forceinline__ int xcd_order(int lin, int nwg)
-{
-    const int q = nwg >> 3, r = nwg & 7, x = lin & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
-}
+// (An XCD-aware workgroup order -- image i's tiles on one XCD in every layer -- measured -0.3 % in round 2, within noise:
+// at 64 frames per graph a layer's tensors are 3 - 50 MB against 4 MB of L2 per XCD.  Removed in round 3.)
 
 template <int KS, int STRIDE, int MT, int NT, bool CIN16, int ACT, bool OUT_F32, bool CT = false, bool DEEP = false>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, int wg_x, int wg_y, int grid_x, int grid_y)
@@ -50,12 +43,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, int wg_x, int 
     static_assert(!CT || (KS == 3 && !CIN16), "chunk-major order is the 3x3 LDS family's");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
-    int bx = wg_x, by = wg_y;
-    if (a.xcd) {   // list order: pixel block major (= image major), then output-channel block
-        const int L = xcd_order(wg_x + wg_y * grid_x, grid_x * grid_y);
-        bx = L / grid_y;
-        by = L - bx * grid_y;
-    }
+    const int bx = wg_x, by = wg_y;
+    (void)grid_x; (void)grid_y;
     const int tile0 = (bx * 4 + wave) * MT;
     const int nt0 = by * NT;
     const int HWo = a.Hout * a.Wout;
@@ -630,14 +619,8 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     //            of staging full-width rows.
     // A workgroup keeps its tile position for `ipw` consecutive images: the staging plan below is computed once,
     // and the load -> LDS -> MFMA pipeline runs through all (image, chunk) steps without draining.
-    int bx = wg_x, by = wg_y;
-    if (a.xcd) {   // list order: image group, then output-channel block, then tile
-        const int tiles = tiles_x * tiles_y, nby = grid_y;
-        const int L = xcd_order(wg_x + wg_y * grid_x, grid_x * nby);
-        const int g_ = L / (tiles * nby), rem = L - g_ * (tiles * nby);
-        by = rem / tiles;
-        bx = g_ * tiles + (rem - by * tiles);
-    }
+    const int bx = wg_x, by = wg_y;
+    (void)grid_x; (void)grid_y;
     const int wg_tiles = PP ? (tiles_x * tiles_y + 1) / 2 : tiles_x * tiles_y;   // tile positions per workgroup column
     const int grp = bx / wg_tiles;
     int tile = PP ? 2 * (bx - grp * wg_tiles) + sub : bx - grp * wg_tiles;
@@ -1322,7 +1305,7 @@ static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int 
 // one pair of barriers.  Same K order as the chunked kernel (chunk, tap) -> bit-identical.
 static LdsGeom wres_geom(const ConvArgs &a, int stride, bool pp)
 {
-    if (stride != 1 || a.Cin != 64 || a.cout_pad != 64 || !a.pair || (a.n2 > 0 && a.res) || a.xcd || !(a.n2 == 0 || a.n2 == 1 || a.n2 == 4)) return LdsGeom{false, 0, 0, 0, 0, 0};
+    if (stride != 1 || a.Cin != 64 || a.cout_pad != 64 || !a.pair || (a.n2 > 0 && a.res) || !(a.n2 == 0 || a.n2 == 1 || a.n2 == 4)) return LdsGeom{false, 0, 0, 0, 0, 0};
     LdsGeom g = pp ? lds_geom(a, 1, 2, 4, 4, 2, true) : lds_geom(a, 1, 2, 4, 8, 2);
     if (pp && !g.tile2d) g.bytes = 0;   // ping-pong groups: 2-D blocks only
     return g;

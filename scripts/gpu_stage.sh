@@ -27,11 +27,6 @@ layers)  SLOTS=64 run layers64 300 python3 scripts/prof_layers.py
 bench)   run bench 600 python3 bench.py ;;
 benchhost) for g in 16 32 64; do IRMV_BENCH_SKIP=latency run benchhost_$g 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --host-group $g; done ;;
 bench2)  IRMV_DIST_BACKEND=gloo IRMV_FORCE_DEVICE=0 run bench2 500 python3 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --frames-per-step 32 ;;
-xcdab)   export IRMV_TUNE_CACHE=$O/tc_xcd.txt; rm -f $IRMV_TUNE_CACHE     # A/B of the XCD-aware workgroup order, one tile table
-         IRMV_XCD=0 SLOTS=64 run layers64_x0 300 python3 scripts/prof_layers.py
-         IRMV_XCD=1 SLOTS=64 run layers64_x1 300 python3 scripts/prof_layers.py
-         IRMV_XCD=0 SLOTS=64 run layers64_x0b 300 python3 scripts/prof_layers.py
-         unset IRMV_TUNE_CACHE ;;
 bench4)  run bench4 600 python3 bench.py --model shufflenet --net 416 --int8 --steps 100 --warmup 10   # BASELINE configs[4]
          grep '^{' $O/bench4.log | tail -1 > $O/bench4.json ;;
 benchq)  run benchq 400 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline ;;
@@ -145,8 +140,7 @@ abwaves) for w in 3 4; do
 tunev)   SLOTS=1 run tune_verbose 300 python3 scripts/tune_verbose.py ;;
 stamps)  TAG=stamps IRMV_NMS_STAMPS=1 run nms_stamps 200 python3 scripts/lat_probe.py ;;
 headerr) run head_error 400 python3 scripts/head_error.py ;;
-lat)     TAG=linear run lat_linear 200 python3 scripts/lat_probe.py
-         TAG=fork_head IRMV_FORK_HEAD=1 run lat_fork 200 python3 scripts/lat_probe.py ;;
+lat)     TAG=linear run lat_linear 200 python3 scripts/lat_probe.py ;;
 repro)   # the round-1 fault sequence, ONCE, under the profiler that exposed it, with every allocation range logged
          cd /tmp; export TMPDIR=/tmp
          IRMV_LOG_ALLOC=1 run repro_prof 300 rocprofv3 --kernel-trace --output-format csv -d $O/repro_prof -- python3 $R/scripts/repro_two_engines.py
