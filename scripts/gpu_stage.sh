@@ -45,6 +45,7 @@ profiles) # everything the round's profiles/ are made of, one tile table for all
          python3 scripts/collect_mfma.py $O/mfma.json $O/pmc_a/*/*_counter_collection.csv $O/pmc_b/*/*_counter_collection.csv
          cp $O/prof_stats/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
          python3 scripts/collect_concurrent.py $O/kernel_stats.csv $O/concurrent.json
+         python3 scripts/timeline.py $O/prof_stats/*/*_kernel_trace.csv > $O/timeline.txt 2>&1; cat $O/timeline.txt
          cd /tmp
          IRMV_STREAMS=1 run prof_stats1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats1 -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 20
          cd $R
