@@ -1236,7 +1236,7 @@ static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int coun
 
 static void cfg_name(const ConvCfg &c, char *buf, int n)
 {
-    if (c.pw) snprintf(buf, n, "conv1x1s1_pw");
+    if (c.pw) snprintf(buf, n, c.ipw > 1 ? "conv1x1s1_pw_n%d" : "conv1x1s1_pw", c.ipw);
     else if (c.wr) snprintf(buf, n, "conv3x3s1_wres%s_i%d", c.pp ? "_pp" : "", c.ipw);
     else if (c.lds && c.ipw > 1) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d_i%d%s%s", c.stride, c.mt, c.nt, c.ipw, c.cm ? "_cm" : (c.pf2 ? "_p2" : ""), c.w8 ? "_w8" : "");
     else if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d%s%s", c.stride, c.mt, c.nt, c.pf2 ? "_p2" : "", c.w8 ? "_w8" : "");
@@ -1307,7 +1307,9 @@ static int autotune_convs(irmv_engine *e)
                     const bool fam_ok = lds_ok ? ((h.lds && !h.ct && !h.deep) || (!h.lds && h.ct && !want_fuse && (!h.deep || counts[pass] == 1)))
                                                : (!h.lds && !h.ct && (!h.deep || counts[pass] == 1 || op.cfg.ks == 1));
                     bool ok = pow2 && op.cout_pad % (16 * h.nt) == 0 && h.ipw <= counts[pass] && fam_ok && (!want_fuse || h.nt == 4);
-                    if (h.pw) ok = !h.lds && !h.ct && !h.deep && h.ipw == 1 && conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW");   // one tile shape
+                    if (h.pw) ok = !h.lds && !h.ct && !h.deep && (h.ipw == 1 || ((h.ipw == 2 || h.ipw == 4) && conv_pw_lds_bytes(a, h.ipw) > 0 && !getenv("IRMV_NO_PWN"))) &&
+                                   conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW");   // one tile shape; ipw = output-channel blocks per workgroup
+                    if (h.pw && ok && getenv("IRMV_FORCE_PWN") && h.ipw == 1 && (conv_pw_lds_bytes(a, 2) > 0 || conv_pw_lds_bytes(a, 4) > 0)) ok = false;   // (parity tests)
                     if (!h.pw && getenv("IRMV_FORCE_PW") && conv_pw_eligible(op.cfg, a)) ok = false;                                  // (parity tests)
                     if (ok && h.lds && !h.wr) {
                         const int li = h.nt == 4 ? 2 : (h.nt == 2 ? 1 : 0);
@@ -1315,7 +1317,7 @@ static int autotune_convs(irmv_engine *e)
                     }
                     if (ok && h.wr) ok = !getenv("IRMV_NO_WRES") && h.lds && !h.pf2 && !h.cm && !h.w8 && h.mt == 2 && h.nt == 4 && op.w_lds[2] && conv_wres_bytes(a, op.cfg.stride, h.pp) > 0;
                     if (ok && getenv("IRMV_FORCE_WRES") && lds_ok && op.w_lds[2] && counts[pass] >= 2 && conv_wres_bytes(a, op.cfg.stride, false) > 0) ok = false;   // parity tests: always the forced form
-                    if (ok && !h.lds) ok = h.ipw == 1;
+                    if (ok && !h.lds && !h.pw) ok = h.ipw == 1;
                     if (ok && h.deep) ok = (h.mt == 1 || (h.mt == 2 && h.nt == 1)) && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1;
                     if (ok && h.ct) ok = op.w_lds[0] != nullptr;
                     if (ok && h.pf2) ok = h.lds && h.mt == 1 && !want_fuse;
@@ -1437,6 +1439,13 @@ static int autotune_convs(irmv_engine *e)
                     c.mt = 2; c.nt = 4; c.lds = false; c.ipw = 1; c.deep = false; c.ct = false; c.pw = true; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                     TRY(time_cfg(c));
                     if (getenv("IRMV_FORCE_PW") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
+                    // ... and its multi-block form: one workgroup runs a pixel tile against 2 / 4 output-channel blocks (input read once)
+                    for (int nbw = 2; nbw <= 4 && !getenv("IRMV_NO_PWN"); nbw *= 2) {
+                        if (!conv_pw_lds_bytes(a, nbw)) continue;
+                        c.ipw = nbw;
+                        TRY(time_cfg(c));
+                        if (getenv("IRMV_FORCE_PWN") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests: the widest form offered
+                    }
                 }
                 // A layer of the LDS family may also run on the direct kernel walking K in that family's order on its weights (ct):
                 // bit-identical, so the family rule above still holds.  Offered where the direct kernel has a chance: stride 2.

@@ -193,7 +193,8 @@ bool conv_pw_eligible(const ConvCfg &cfg, const ConvArgs &a);
 // 1x1 fp32 bias-only; mt = nt = 1).  false: some member has no such tile.
 bool launch_conv_lds_multi(int nt, const ConvArgs *a, const half_t *const *wl, int n, int batch, hipStream_t s);
 bool launch_conv_direct_multi(const ConvCfg &cfg, const ConvArgs *a, int n, hipStream_t s);
-bool launch_conv_pw(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);
+bool launch_conv_pw(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);   // cfg.ipw = NBW: 64-channel output blocks per workgroup (1: the single-block kernel)
+size_t conv_pw_lds_bytes(const ConvArgs &a, int nbw);                        // NBW = 2 / 4: LDS of the multi-block form, 0 = not offered
 // LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt
 size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_rows_max, bool w8 = false);
 // weights-resident variant: bytes of LDS (0 = not eligible), tile positions per image and workgroup column, launcher

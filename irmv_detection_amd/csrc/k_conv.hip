@@ -435,6 +435,7 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
     }
     const int HWo = a.Hout * a.Wout;
     const int H0 = a.Hin >> a.s0.shift, W0 = a.Win >> a.s0.shift, H1 = a.Hin >> a.s1.shift, W1 = a.Win >> a.s1.shift;
+    const bool flat = a.s0.shift == 0 && a.s1.shift == 0;
     float bias[2][8];
 #pragma unroll
     for (int u = 0; u < 2; u++)
@@ -457,10 +458,16 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
             const int m = (ub + mt) * 16 + r;
             mv[mt] = ub + mt < u1 && m < a.M;
             const int mm = mv[mt] ? m : 0;
-            const int b = mm / HWo, rem = mm - b * HWo;
-            const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
-            p0[mt] = a.s0.p + ((size_t)(b * H0 + (oy >> a.s0.shift)) * W0 + (ox >> a.s0.shift)) * a.s0.ld + 8 * g;
-            p1[mt] = a.s1.p + ((size_t)(b * H1 + (oy >> a.s1.shift)) * W1 + (ox >> a.s1.shift)) * a.s1.ld + 8 * g - a.s0.C;
+            if (flat) {   // no half-resolution segment (every layer but the neck's upsample + concat readers): pixel m of the output
+                          // is pixel m of both segments -- no (image, row, column) split: two integer divisions per unit less
+                p0[mt] = a.s0.p + (size_t)mm * a.s0.ld + 8 * g;
+                p1[mt] = a.s1.p + (size_t)mm * a.s1.ld + 8 * g - a.s0.C;
+            } else {
+                const int b = mm / HWo, rem = mm - b * HWo;
+                const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+                p0[mt] = a.s0.p + ((size_t)(b * H0 + (oy >> a.s0.shift)) * W0 + (ox >> a.s0.shift)) * a.s0.ld + 8 * g;
+                p1[mt] = a.s1.p + ((size_t)(b * H1 + (oy >> a.s1.shift)) * W1 + (ox >> a.s1.shift)) * a.s1.ld + 8 * g - a.s0.C;
+            }
         }
     };
     // UNCONDITIONAL: a pixel past the end reads pixel 0 (tile_ptrs clamps) into a B column whose results are never stored.
@@ -539,6 +546,139 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
     if (ub < u1) run_tile(std::integral_constant<int, 1>{}, std::false_type{}, ub);
 }
 
+// Pointwise kernel, several output-channel blocks per workgroup (NBW blocks of 64 channels): the kernel above gives every
+// 64-channel block its own workgroups, so a layer with 128 / 256 output channels reads its input two / four times (from L2
+// the second time on, but every read is a request the CU's vector-memory path has to carry).  Here ONE 8-wave workgroup
+// keeps the weights of NBW blocks in LDS (NBW x KS x 4 KiB: up to 128 KiB, one workgroup per CU) and a wave runs the B
+// fragments of its pixel tile -- loaded ONCE -- against all of them, block after block; the fragments of the wave's next
+// tile are requested during the last block's pass.  Per output channel the k order is the kernel's above -> bit-identical.
+template <int KS, int NBW>
+__global__ __launch_bounds__(512) void conv1x1_pwn_kernel(ConvArgs a, int wg_per_group)
+{
+    constexpr int MT = 2, NT = 4, NTH = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8 *s_w = reinterpret_cast<half8 *>(smem);                                   // [NBW][NT][KS][64 lanes]
+    float *s_bias = reinterpret_cast<float *>(smem + (size_t)NBW * NT * KS * 1024); // [NBW][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int nblk0 = blockIdx.y * NBW;
+    constexpr int WALL = NBW * NT * KS * 64, WPT = (WALL + NTH - 1) / NTH;          // half8 pieces, per thread (<= 16)
+    half8 wreg[WPT];
+    {
+        const half8 *wsrc = reinterpret_cast<const half8 *>(a.w) + (size_t)nblk0 * NT * KS * 64;
+#pragma unroll
+        for (int i = 0; i < WPT; i++) {
+            const int e = tid + i * NTH;
+            wreg[i] = wsrc[e < WALL ? e : WALL - 1];
+        }
+    }
+    if (tid < NBW * 64) s_bias[tid] = a.bias[nblk0 * 64 + tid];
+    const int HWo = a.Hout * a.Wout;
+    const int H0 = a.Hin >> a.s0.shift, W0 = a.Win >> a.s0.shift, H1 = a.Hin >> a.s1.shift, W1 = a.Win >> a.s1.shift;
+    const bool flat = a.s0.shift == 0 && a.s1.shift == 0;
+    const int units = (a.M + 15) >> 4, nw = wg_per_group * 8, wv = blockIdx.x * 8 + wave;
+    const int u0 = (int)((long long)wv * units / nw), u1 = (int)((long long)(wv + 1) * units / nw);
+    const half_t *p0[MT], *p1[MT];
+    bool mv[MT];
+    auto tile_ptrs = [&](int ub) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int m = (ub + mt) * 16 + r;
+            mv[mt] = ub + mt < u1 && m < a.M;
+            const int mm = mv[mt] ? m : 0;
+            if (flat) {   // no half-resolution segment (every layer but the neck's upsample + concat readers): pixel m of the output
+                          // is pixel m of both segments -- no (image, row, column) split: two integer divisions per unit less
+                p0[mt] = a.s0.p + (size_t)mm * a.s0.ld + 8 * g;
+                p1[mt] = a.s1.p + (size_t)mm * a.s1.ld + 8 * g - a.s0.C;
+            } else {
+                const int b = mm / HWo, rem = mm - b * HWo;
+                const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+                p0[mt] = a.s0.p + ((size_t)(b * H0 + (oy >> a.s0.shift)) * W0 + (ox >> a.s0.shift)) * a.s0.ld + 8 * g;
+                p1[mt] = a.s1.p + ((size_t)(b * H1 + (oy >> a.s1.shift)) * W1 + (ox >> a.s1.shift)) * a.s1.ld + 8 * g - a.s0.C;
+            }
+        }
+    };
+    auto load_b = [&](int mt, int ks) -> half8 {   // unconditional (see conv1x1_pw_kernel)
+        const int c = ks * 32;
+        return *reinterpret_cast<const half8 *>((c < a.s0.C ? p0[mt] : p1[mt]) + c);
+    };
+    half8 B[MT][KS];
+    tile_ptrs(u0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) B[mt][ks] = load_b(mt, ks);
+#pragma unroll
+    for (int i = 0; i < WPT; i++) {
+        const int e = tid + i * NTH;
+        if (e < WALL) s_w[e] = wreg[i];
+    }
+    __syncthreads();                                             // weights and biases staged
+    half_t *out = static_cast<half_t *>(a.out);
+    auto run_tile = [&](auto mta_c, auto pre_c, int ub) {
+        constexpr int MTA = decltype(mta_c)::value;
+        constexpr bool PRE = decltype(pre_c)::value;
+        size_t m_cur[MTA];
+        bool mv_cur[MTA];
+#pragma unroll
+        for (int mt = 0; mt < MTA; mt++) { m_cur[mt] = (size_t)(ub + mt) * 16 + r; mv_cur[mt] = mv[mt]; }
+        if constexpr (PRE) tile_ptrs(ub + MT);                   // from here p0 / p1 / mv describe the NEXT tile
+#pragma unroll
+        for (int nb = 0; nb < NBW; nb++) {
+            const half8 *s_wb = s_w + nb * (NT * KS * 64) + lane;
+            f32x4 acc[MTA][NT];
+#pragma unroll
+            for (int mt = 0; mt < MTA; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            half8 A[2][NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) A[0][nt] = s_wb[(nt * KS) * 64];
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) A[(ks + 1) & 1][nt] = s_wb[(nt * KS + ks + 1) * 64];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MTA; mt++) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks & 1][nt], B[mt][ks], acc[mt][nt], 0, 0, 0);
+                    if constexpr (PRE) if (nb == NBW - 1) B[mt][ks] = load_b(mt, ks);   // last pass over this tile's fragments: fetch the next tile's
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float bias[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(s_bias + nb * 64 + u * 32 + g * 8), b1 = *reinterpret_cast<const f32x4 *>(s_bias + nb * 64 + u * 32 + g * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { bias[u][i] = b0[i]; bias[u][4 + i] = b1[i]; }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTA; mt++) {
+                if (!mv_cur[mt]) continue;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    float vals[8];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        vals[i] = acc[mt][2 * u][i] + bias[u][i];
+                        vals[4 + i] = acc[mt][2 * u + 1][i] + bias[u][4 + i];
+                    }
+                    half8 o;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o[i] = (half_t)(vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i])));
+                    *reinterpret_cast<half8 *>(out + m_cur[mt] * a.out_ld + ((nblk0 + nb) * 2 + u) * 32 + g * 8) = o;
+                }
+            }
+        }
+    };
+    int ub = u0;
+    for (; ub + MT <= u1; ub += MT) run_tile(std::integral_constant<int, MT>{}, std::true_type{}, ub);
+    if (ub < u1) run_tile(std::integral_constant<int, 1>{}, std::false_type{}, ub);
+}
+
 // eligible: 1x1, SiLU, fp16 out, pair-packed, 64 | cout, K a multiple of 32 with 4..16 k-steps, first segment a multiple of 32
 bool conv_pw_eligible(const ConvCfg &c, const ConvArgs &a)
 {
@@ -546,10 +686,45 @@ bool conv_pw_eligible(const ConvCfg &c, const ConvArgs &a)
            (a.ksteps == 4 || a.ksteps == 6 || a.ksteps == 8 || a.ksteps == 12 || a.ksteps == 16) && a.res == nullptr && a.n2 == 0;
 }
 
+// LDS of the multi-block form: NBW weight slabs + NBW x 64 biases; 0 = this (KS, NBW) is not offered
+size_t conv_pw_lds_bytes(const ConvArgs &a, int nbw)
+{
+    if (!(nbw == 2 || nbw == 4) || a.cout_pad % (64 * nbw) != 0) return 0;
+    const int ks = a.ksteps;
+    if (!(ks == 4 || ks == 6 || ks == 8 || ks == 12 || ks == 16) || nbw * ks > 32) return 0;   // <= 128 KiB of weights, <= 16 staging pieces per thread
+    return (size_t)nbw * 4 * ks * 1024 + (size_t)nbw * 64 * 4;
+}
+
 bool launch_conv_pw(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
 {
     if (!conv_pw_eligible(c, a)) return false;
     const int tiles_total = (a.M + 31) / 32, nblocks = a.cout_pad / 64;
+    if (c.ipw > 1) {   // several output-channel blocks per workgroup (c.ipw = NBW): the input is read nblocks / NBW times
+        const int nbw = c.ipw;
+        const size_t lds = conv_pw_lds_bytes(a, nbw);
+        if (!lds) return false;
+        const int groups = nblocks / nbw;
+        const int units = (a.M + 15) / 16;
+#define IRMV_PWN(KS_, NBW_)                                                                                          \
+        if (a.ksteps == KS_ && nbw == NBW_) {                                                                          \
+            static unsigned long long attr_done = 0;                                                                   \
+            static int per_cu = 1;   /* workgroups a CU holds (registers and LDS): sizes the grid to one round */       \
+            once_per_device(attr_done, [lds] {                                                                         \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_pwn_kernel<KS_, NBW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                int nb = 0;                                                                                            \
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(conv1x1_pwn_kernel<KS_, NBW_>), 512, lds) == hipSuccess && nb >= 1) per_cu = nb > 2 ? 2 : nb; \
+            });                                                                                                        \
+            int wg = (256 * per_cu + groups - 1) / groups;               /* the chip in one round ... */               \
+            if (wg > (units + 7) / 8) wg = (units + 7) / 8;              /* ... but a 16-pixel unit per wave at least (20 x 20 maps: more  \
+                                                                            workgroups beat longer pipelines: 2 / 3 units per wave +7 / +25 %) */ \
+            if (wg < 1) wg = 1;                                                                                        \
+            hipLaunchKernelGGL((conv1x1_pwn_kernel<KS_, NBW_>), dim3(wg, groups), dim3(512), lds, s, a, wg);           \
+            return true;                                                                                               \
+        }
+        IRMV_PWN(4, 2) IRMV_PWN(6, 2) IRMV_PWN(8, 2) IRMV_PWN(12, 2) IRMV_PWN(16, 2) IRMV_PWN(4, 4) IRMV_PWN(6, 4) IRMV_PWN(8, 4)
+#undef IRMV_PWN
+        return false;
+    }
     // ~2 workgroups per CU in total, never more workgroups than there are 4-tile rounds
     int wg = (tiles_total + 3) / 4;
     const int cap = (512 + nblocks - 1) / nblocks;

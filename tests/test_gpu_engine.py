@@ -410,21 +410,30 @@ def test_pointwise_kernel_is_bitwise_the_direct_kernel(blob, monkeypatch):
     may replace: same operands, same k order -> same bits, batched (partial last tiles included: 3 frames) and single-frame."""
     imgs = [frames.synthetic_frame(40 + i) for i in range(3)]
     heads = {}
-    for mode in ("IRMV_FORCE_PW", "IRMV_NO_PW"):
-        monkeypatch.delenv("IRMV_FORCE_PW", raising=False)
-        monkeypatch.delenv("IRMV_NO_PW", raising=False)
+    # IRMV_FORCE_PWN: the multi-block form (one 8-wave workgroup runs a pixel tile against 2 / 4 output-channel blocks whose
+    # weights all sit in LDS; the input is read once instead of once per block) wherever it is offered
+    for mode in ("IRMV_FORCE_PW", "IRMV_FORCE_PWN", "IRMV_NO_PW"):
+        for m in ("IRMV_FORCE_PW", "IRMV_FORCE_PWN", "IRMV_NO_PW", "IRMV_NO_PWN"):
+            monkeypatch.delenv(m, raising=False)
         monkeypatch.setenv(mode, "1")
+        if mode == "IRMV_FORCE_PW":
+            monkeypatch.setenv("IRMV_NO_PWN", "1")
         with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3, num_streams=1) as e:
             names = [st["name"] for st in e.profile(0, 3)] + [st["name"] for st in e.profile(0, 1)]
             assert any(n == "conv1x1s1_pw" for n in names) == (mode == "IRMV_FORCE_PW"), (mode, names)
+            assert (sum(n.startswith("conv1x1s1_pw_n") for n in names) >= 10) == (mode == "IRMV_FORCE_PWN"), (mode, names)
+            if mode == "IRMV_FORCE_PWN":
+                assert any(n == "conv1x1s1_pw_n4" for n in names) and any(n == "conv1x1s1_pw_n2" for n in names), names
             for s, im in enumerate(imgs):
                 _load(e, s, im)
             e.submit(0, 3); e.wait()
             batched = [e.read_head(s).copy() for s in range(3)]
+            taps = [e.read_tap(t, 2).copy() for t in ("6", "8", "9", "12", "18", "21")]
             e.detect(1)
-            heads[mode] = batched + [e.read_head(1).copy()]
-    for a, b in zip(heads["IRMV_FORCE_PW"], heads["IRMV_NO_PW"]):
-        assert np.array_equal(a, b)
+            heads[mode] = batched + [e.read_head(1).copy()] + taps
+    for mode in ("IRMV_FORCE_PW", "IRMV_FORCE_PWN"):
+        for a, b in zip(heads[mode], heads["IRMV_NO_PW"]):
+            assert np.array_equal(a, b), mode
     assert np.array_equal(heads["IRMV_FORCE_PW"][1], heads["IRMV_FORCE_PW"][3])
 
 
