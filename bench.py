@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames-per-step", type=int, default=192)
+    ap.add_argument("--frames-per-step", type=int, default=256)
     ap.add_argument("--src", default="1280x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96)
@@ -310,7 +310,7 @@ def main():
         def prof_name(n):   # bench name -> the name the profile reducers give the kernel symbol (launch-time options dropped)
             return re.sub(r"_i\d+|_cm|_w8|_p2", "", n)
         base_name = prof_name(dom_name)
-        default_cfg = (args.model, args.net, args.int8) == ("yolov8n", 640, False) and per_graph == 64   # what the counter files were collected on: 64-frame graphs
+        default_cfg = (args.model, args.net, args.int8) == ("yolov8n", 640, False) and per_graph == 128   # what the counter files were collected on: 128-frame graphs
         for tname in (("r03_traffic.json", "r02_traffic.json", "r01_traffic.json") if default_cfg else ()):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):

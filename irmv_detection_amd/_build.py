@@ -26,8 +26,11 @@ SOURCES = [
     ("k_shuffle.hip", []),
     ("engine.cpp", ["-x", "hip"]),
 ]
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs.  Left to itself the compiler gives kernels without a waves_per_eu
+# bound (fused C2f blocks, direct convs) AGPR accumulators and copies every one of them out with a v_accvgpr_read before the
+# epilogue: one vector instruction per output value in kernels whose vector-issue slots are the scarce resource.
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
-          "-I", INCLUDE]
+          "-mllvm", "-amdgpu-mfma-vgpr-form", "-I", INCLUDE]
 
 
 def hipcc() -> str:

@@ -676,7 +676,8 @@ static int build_engine(irmv_engine *e)
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     // default: batched engines replay concurrent sub-batches of ~64 frames, two to four of them; a stream per slot
     // for engines of TripleBuffer size, whose single-slot steps then overlap
-    e->num_streams = c.num_streams > 0 ? c.num_streams : (c.num_slots <= 4 ? c.num_slots : std::min(4, std::max(2, (c.num_slots + 63) / 64)));   // batched: graphs of ~64 frames
+    e->num_streams = c.num_streams > 0 ? c.num_streams : (c.num_slots <= 4 ? c.num_slots : std::min(4, std::max(2, (c.num_slots + 127) / 128)));   // batched: two graphs of up to 128 frames (round 3: with the
+                                                                                                                                                   // weights-resident / multi-block kernels larger graphs win: 256 frames as 2 x 128 +6 % over 192 as 3 x 64)
     if (const char *ns = getenv("IRMV_STREAMS")) e->num_streams = atoi(ns);
     e->num_streams = std::max(1, std::min({e->num_streams, 8, c.num_slots}));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));

@@ -36,10 +36,10 @@ profiles) # everything the round's profiles/ are made of, one tile table for all
          grep '^{' $O/bench.log | tail -1 > $O/bench.json
          cd /tmp; export TMPDIR=/tmp
          IRMV_BENCH_SKIP=latency,h2d run prof_stats 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline
-         IRMV_STREAMS=1 run pmc_f 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
-         IRMV_STREAMS=1 run pmc_w 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
-         IRMV_STREAMS=1 run pmc_a 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
-         IRMV_STREAMS=1 run pmc_b 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_f 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
+         IRMV_STREAMS=1 run pmc_w 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
+         IRMV_STREAMS=1 run pmc_a 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
+         IRMV_STREAMS=1 run pmc_b 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
          cd $R
          python3 scripts/collect_traffic.py $O/pmc_f/*/*_counter_collection.csv $O/pmc_w/*/*_counter_collection.csv $O/traffic.json
          python3 scripts/collect_mfma.py $O/mfma.json $O/pmc_a/*/*_counter_collection.csv $O/pmc_b/*/*_counter_collection.csv
@@ -47,7 +47,7 @@ profiles) # everything the round's profiles/ are made of, one tile table for all
          python3 scripts/collect_concurrent.py $O/kernel_stats.csv $O/concurrent.json
          python3 scripts/timeline.py $O/prof_stats/*/*_kernel_trace.csv > $O/timeline.txt 2>&1; cat $O/timeline.txt
          cd /tmp
-         IRMV_STREAMS=1 run prof_stats1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats1 -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 20
+         IRMV_STREAMS=1 run prof_stats1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats1 -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 20
          cd $R
          cp $O/prof_stats1/*/*_kernel_stats.csv $O/kernel_stats_single_stream.csv 2>/dev/null
          rm -rf $O/prof_stats1 $O/prof_stats $O/pmc_f $O/pmc_w $O/pmc_a $O/pmc_b     # raw traces: tens of MB; the reductions above are what is kept
@@ -56,7 +56,7 @@ profiles) # everything the round's profiles/ are made of, one tile table for all
          grep '^{' $O/bench4.log | tail -1 > $O/bench4.json ;;
 stats1)  export IRMV_TUNE_CACHE=$R/profiles/r02_tune_cache.txt   # single-stream eager trace with the committed tile table
          cd /tmp; export TMPDIR=/tmp
-         IRMV_STREAMS=1 run prof_stats1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats1 -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 20
+         IRMV_STREAMS=1 run prof_stats1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats1 -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 20
          cd $R
          cp $O/prof_stats1/*/*_kernel_stats.csv $O/kernel_stats_single_stream.csv 2>/dev/null
          rm -rf $O/prof_stats1
@@ -66,13 +66,13 @@ stats)   export IRMV_TUNE_CACHE=$O/tune_cache.txt
          IRMV_BENCH_SKIP=latency,h2d run prof_stats 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline
          cd $R ;;
 pmc)     cd /tmp; export TMPDIR=/tmp
-         IRMV_STREAMS=1 run pmc_a 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
-         IRMV_STREAMS=1 run pmc_b 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_a 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
+         IRMV_STREAMS=1 run pmc_b 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
          cd $R
          python3 scripts/collect_mfma.py $O/mfma.json $O/pmc_a/*/*_counter_collection.csv $O/pmc_b/*/*_counter_collection.csv ;;
 traffic) cd /tmp; export TMPDIR=/tmp
-         IRMV_STREAMS=1 run pmc_f 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
-         IRMV_STREAMS=1 run pmc_w 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_f 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
+         IRMV_STREAMS=1 run pmc_w 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
          cd $R
          python3 scripts/collect_traffic.py $O/pmc_f/*/*_counter_collection.csv $O/pmc_w/*/*_counter_collection.csv $O/traffic.json ;;
 probe)   run probe_build 120 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 scripts/probes/stream_probe.cpp -o $O/stream_probe
@@ -114,9 +114,9 @@ crashprobe) cd /tmp; export TMPDIR=/tmp
          cd $R ;;
 s2probe) NET=416 run s2_probe 300 python3 scripts/s2_probe.py ;;
 pmc1x1)  cd /tmp; export TMPDIR=/tmp
-         IRMV_STREAMS=1 run pmc_pw_a 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_pw_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
-         IRMV_STREAMS=1 run pmc_pw_b 300 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_pw_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
-         IRMV_STREAMS=1 run pmc_pw_c 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum --kernel-trace --output-format csv -d $O/pmc_pw_c -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 64 --steps 2
+         IRMV_STREAMS=1 run pmc_pw_a 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_pw_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
+         IRMV_STREAMS=1 run pmc_pw_b 300 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_pw_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
+         IRMV_STREAMS=1 run pmc_pw_c 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum --kernel-trace --output-format csv -d $O/pmc_pw_c -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
          cd $R
          python3 - <<PY > $O/pmc_pw_summary.txt 2>&1
 import csv, glob, collections
