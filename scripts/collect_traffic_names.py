@@ -17,6 +17,9 @@ def internal_name(sym):
         ks, st, mt, nt, c16, act, f32, ct, deep = m.groups()
         return (f"conv{ks}x{ks}s{st}_mt{mt}_nt{nt}" + ("_c16" if c16 == "true" else "") + ("_f32" if f32 == "true" else "") +
                 ("_deep" if deep == "true" else "") + ("_ct" if ct == "true" else ""))
+    m = re.search(r"conv1x1_pwn_kernel<(\d+), (\d)>", sym) or re.search(r"conv1x1_pwn_kernelILi(\d+)ELi(\d)EE", sym)
+    if m:   # multi-block pointwise kernel (round 3): <KS, NBW>
+        return f"conv1x1s1_pw_n{m.group(2)}"
     if "conv1x1_pw_kernel" in sym:
         return "conv1x1s1_pw"
     m = re.search(r"c2f32_kernel<(\d), (\d), (true|false)>", sym)
