@@ -205,10 +205,14 @@ def main():
     # weights: rank 0 generates, everyone receives by ONE broadcast (RCCL over xGMI)
     blob = make_blob(args) if rank == 0 else None
     backbone = arch.BACKBONE_SHUFFLE if args.model == "shufflenet" else arch.BACKBONE_C2F
-    if world > 1:
-        w_ptr, w_bytes = R.broadcast_blob(blob)       # device buffer owned by the communicator, alive until R.close()
-        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=w_ptr, weights_bytes=w_bytes, num_slots=B, net_size=args.net)
+    bc = R.broadcast_blob(blob) if world > 1 else None    # device buffer owned by the communicator, alive until R.close()
+    weights_via = "one RCCL broadcast from rank 0 (libirmv_comm.so)" if bc else ("generated in process" if world == 1 else
+                  "RCCL NOT AVAILABLE on this node: every rank generated the same seeded blob; barriers and clocks through files")
+    if bc:
+        eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=bc[0], weights_bytes=bc[1], num_slots=B, net_size=args.net)
     else:
+        if blob is None:
+            blob = make_blob(args)
         eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=B, net_size=args.net)
 
     # this rank's frames: round-robin over the global frame index, made resident in HBM once
@@ -387,7 +391,7 @@ def main():
                                    f" (nc=14, 4-kpt head, seeded {'int8-container weights expanded to fp16 at load: int8 storage / broadcast, fp16 compute' if args.int8 else 'fp16 weights'}) -> decode+NMS -> IPPE PnP; "
                                    f"{B} independent frames per step per GPU as {eng.num_streams} concurrently replayed hipGraphs "
                                    + ("(BASELINE configs[1]/[2])" if (args.model, args.net, args.int8) == ("yolov8n", 640, False) else "(BASELINE configs[4] family; NOT the configuration the metric is quoted on)"),
-                       "frames_per_step_per_gpu": B, "streams_per_gpu": eng.num_streams, "src": f"{sw}x{sh}", "net": args.net, "parallelism": f"dp{world} (replicas, frames sharded)",
+                       "frames_per_step_per_gpu": B, "streams_per_gpu": eng.num_streams, "src": f"{sw}x{sh}", "net": args.net, "parallelism": f"dp{world} (replicas, frames sharded)", "weights": weights_via,
                        "gflop_per_frame": round(arch.flops_per_frame(args.net, backbone=backbone) / 1e9, 3), "detections_last_step_rank0": n_dets},
             "roofline": roofline,
         }

@@ -95,29 +95,97 @@ def exchange_id(rank: int, make_id, path: Optional[str] = None, timeout_s: float
         time.sleep(0.02)
 
 
+class FileReduce:
+    """Reductions of one float per rank through small files (single node): the side channel that carries the communicator
+    id also carries the ranks' agreement on whether RCCL came up, and -- if it did not -- the bench's barriers and clocks,
+    so that a node where RCCL cannot initialise still yields per-GPU numbers (reported as such; the weight broadcast is
+    then replaced by every rank generating the same seeded blob)."""
+
+    def __init__(self, rank: int, world: int, base: str):
+        self.rank, self.world, self.base, self.seq = rank, world, base, 0
+
+    def gather(self, x: float, timeout_s: float = 600.0) -> List[float]:
+        self.seq += 1
+        mine = f"{self.base}.r{self.seq}.{self.rank}"
+        tmp = mine + ".tmp"
+        with open(tmp, "w") as f:
+            f.write(repr(float(x)))
+        os.replace(tmp, mine)
+        vals, t0 = [], time.time()
+        for r in range(self.world):
+            path = f"{self.base}.r{self.seq}.{r}"
+            while True:
+                try:
+                    with open(path) as f:
+                        vals.append(float(f.read()))
+                    break
+                except (FileNotFoundError, ValueError):
+                    if time.time() - t0 > timeout_s:
+                        raise CommError(f"rank {self.rank}: rank {r} never reached reduction {self.seq}")
+                    time.sleep(0.002)
+        if self.seq > 2:        # everybody has read round seq - 2 by now (they wrote seq - 1 after reading it)
+            old = f"{self.base}.r{self.seq - 2}.{self.rank}"
+            if os.path.exists(old):
+                os.remove(old)
+        return vals
+
+    def close(self) -> None:
+        """A last round as the closing handshake: once it is complete every rank has read everything before it, so those
+        files go; the closing round's own file (a few bytes per rank) stays -- a peer may not have read it yet."""
+        self.gather(0.0)
+        for q in (self.seq - 2, self.seq - 1):
+            path = f"{self.base}.r{q}.{self.rank}"
+            if q > 0 and os.path.exists(path):
+                os.remove(path)
+
+
 class Comm:
     """One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher).  With one rank nothing is loaded and every
-    call is the identity."""
+    call is the identity.  `native` tells whether the RCCL communicator is up on EVERY rank (the ranks agree on it through
+    the file channel); if not, reductions fall back to that channel and broadcast_blob() returns None."""
 
     def __init__(self):
         self.rank, self.local_rank, self.world = env_rank_world()
         self.device = device_index(self.local_rank)
         self._h = C.c_void_p()
         self._id_path = None
+        self._files = None
+        self.native = self.world > 1
+        self.native_error = None
         if self.world > 1:
-            L = load()
-
-            def make():
-                buf = C.create_string_buffer(ID_BYTES)
-                _check(L.irmv_comm_unique_id(buf))
-                return buf.raw
             self._id_path = id_file()
-            uid = exchange_id(self.rank, make, self._id_path)
-            _check(L.irmv_comm_init_rank(uid, self.world, self.rank, self.device, C.byref(self._h)))
+            self._files = FileReduce(self.rank, self.world, self._id_path)
+            ok = 1.0
+            try:
+                L = load()
 
-    def broadcast_blob(self, blob: Optional[bytes], root: int = 0) -> Tuple[int, int]:
-        """-> (device pointer, bytes) of the blob on this rank's GPU (communicator-owned).  Only `root` passes bytes."""
+                def make():
+                    buf = C.create_string_buffer(ID_BYTES)
+                    _check(L.irmv_comm_unique_id(buf))
+                    return buf.raw
+                uid = exchange_id(self.rank, make, self._id_path)
+                if uid == bytes(ID_BYTES):
+                    raise CommError("rank 0 could not create a communicator id")
+                _check(L.irmv_comm_init_rank(uid, self.world, self.rank, self.device, C.byref(self._h)))
+            except (CommError, OSError) as e:       # RCCL refused (or the library is missing): say so, then agree with the others
+                ok, self.native_error = 0.0, str(e)
+                if self.rank == 0 and not os.path.exists(self._id_path):   # the others are waiting for an id: give them a dummy
+                    exchange_id(0, lambda: bytes(ID_BYTES), self._id_path)
+            self.native = min(self._files.gather(ok)) > 0.5
+            if not self.native:
+                import sys
+                print(f"[irmv_comm] rank {self.rank}: RCCL communicator not available on every rank"
+                      f"{' (' + self.native_error + ')' if self.native_error else ''}: file-based reductions, no weight broadcast", file=sys.stderr, flush=True)
+                if self._h:
+                    load().irmv_comm_destroy(self._h)
+                    self._h = C.c_void_p()
+
+    def broadcast_blob(self, blob: Optional[bytes], root: int = 0) -> Optional[Tuple[int, int]]:
+        """-> (device pointer, bytes) of the blob on this rank's GPU (communicator-owned).  Only `root` passes bytes.
+        None when the RCCL communicator is not up (every rank then builds the blob itself)."""
         assert self.world > 1
+        if not self.native:
+            return None
         L = load()
         ptr, n = C.c_void_p(), C.c_uint64()
         if self.rank == root:
@@ -131,6 +199,9 @@ class Comm:
     def _reduce(self, x: float, op: int) -> float:
         if self.world == 1:
             return float(x)
+        if not self.native:
+            vals = self._files.gather(x)
+            return float(max(vals) if op == 1 else sum(vals))
         v = C.c_double(x)
         _check(load().irmv_comm_allreduce_f64(self._h, C.byref(v), op))
         return float(v.value)
@@ -148,5 +219,7 @@ class Comm:
         if self._h:
             load().irmv_comm_destroy(self._h)
             self._h = C.c_void_p()
+        if self._files:
+            self._files.close()
         if self.rank == 0 and self._id_path and os.path.exists(self._id_path):
             os.remove(self._id_path)

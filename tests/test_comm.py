@@ -71,6 +71,29 @@ def test_communicator_id_reaches_the_other_rank(tmp_path):
     assert p.exitcode == 0
 
 
+def _reducer(rank, base, q):
+    fr = comm.FileReduce(rank, 2, base)
+    out = [fr.gather(float(rank + 1)), fr.gather(10.0 * (rank + 1)), fr.gather(0.5), fr.gather(float(rank))]
+    fr.close()
+    q.put((rank, out))
+
+
+def test_file_channel_reductions_between_two_processes(tmp_path):
+    """The fallback the bench's ranks agree on when RCCL cannot come up on a node: every rank sees every rank's value."""
+    base = str(tmp_path / "chan")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_reducer, args=(r, base, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in ps:
+        p.join(30)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == [[1.0, 2.0], [10.0, 20.0], [0.5, 0.5], [0.0, 1.0]]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("chan.r")) == ["chan.r5.0", "chan.r5.1"]   # only the closing handshake's files stay
+
+
 def test_one_rank_is_the_identity(monkeypatch):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
