@@ -165,7 +165,6 @@ struct Op {
     double flops = 0, bytes = 0;  // per frame (bytes: activations in + out, plus the weights)
     double w_bytes = 0;           // the weights' share of `bytes`: read once per LAUNCH, not once per frame (irmv_engine_profile)
     double out_bytes = 0;         // the output's share (a conv that carries a fused 1x1 writes that layer's output instead of its own)
-    int c2f_tile_h[2] = {8, 8};   // OP_C2F32: tile height of batched / single-frame steps (8 or 16; timed at engine creation, bitwise neutral)
     bool pair = false;
     int lane = 0;      // 0 = trunk; 1..3 = Detect branch (box / cls / kpt): which grouped launch a head conv may join
     int level = -1;    // Detect level of a head op: it may start as soon as P(level) exists
@@ -666,7 +665,6 @@ static bool front_fits(const std::vector<AxisTap> &tx, const std::vector<AxisTap
 }
 
 static int autotune_convs(irmv_engine *e);
-static int tune_c2f_tiles(irmv_engine *e);
 static void finalize_head_fusion(irmv_engine *e);
 static int build_head_groups(irmv_engine *e);
 
@@ -1160,8 +1158,6 @@ extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
     rc = build_engine(e.get());
     if (rc) return rc;
     rc = autotune_convs(e.get());
-    if (rc) return rc;
-    rc = tune_c2f_tiles(e.get());
     if (rc) return rc;
     finalize_head_fusion(e.get());
     rc = build_head_groups(e.get());
@@ -1736,8 +1732,10 @@ static PostArgs post_args(const irmv_engine *e, int first)
 }
 
 // Enqueue one step on the engine stream.  ev != nullptr: bracket every kernel with events.
-// one fused C2f block (OP_C2F32) with tiles of height tile_h (8 or 16): same arithmetic per pixel either way
-static bool launch_c2f32_op(const irmv_engine *e, const Op &op, int first, int count, int tile_h, hipStream_t s)
+// one fused C2f block (OP_C2F32).  (A 16 x 16 tile on an 8-wave workgroup -- a third less halo work, one workgroup per CU --
+// was built and measured in round 3: 5 - 30 % slower than the 8 x 16 tile in an eager replay, a tie in the benchmarked one;
+// dropped.)
+static bool launch_c2f32_op(const irmv_engine *e, const Op &op, int first, int count, hipStream_t s)
 {
     C2f32Args a{};
     const Tensor &ct = e->tensors[op.res_t];
@@ -1753,54 +1751,11 @@ static bool launch_c2f32_op(const irmv_engine *e, const Op &op, int first, int c
     a.cat = static_cast<half_t *>(ct.slot(first)); a.cat_ld = ct.C; a.prev_coff = 64;
     a.out = static_cast<half_t *>(ot.slot(first)); a.out_ld = ot.C;
     a.H = op.Hin; a.W = op.Win;
-    a.tile_h = tile_h;
-    a.tiles_x = (op.Win + kC2f32TileW - 1) / kC2f32TileW; a.tiles_y = (op.Hin + tile_h - 1) / tile_h;
+    a.tiles_x = (op.Win + kC2f32TileW - 1) / kC2f32TileW; a.tiles_y = (op.Hin + kC2f32TileH - 1) / kC2f32TileH;
     a.w_m1 = e->ops[op.sub[1]].w_packed; a.b_m1 = e->ops[op.sub[1]].bias;
     a.w_m2 = e->ops[op.sub[2]].w_packed; a.b_m2 = e->ops[op.sub[2]].bias;
     if (op.sub[3] >= 0) { a.w_cv2 = e->ops[op.sub[3]].w_packed; a.b_cv2 = e->ops[op.sub[3]].bias; }
     return launch_c2f32(op.mode, op.shortcut, a, count, s);
-}
-
-// Tile height of the fused C2f blocks, by measurement (both heights give the same bits): 16 = an 8-wave workgroup with
-// a third less halo work, one per CU; 8 = twice the workgroups.  IRMV_C2F_TILE=8|16 pins it (parity tests).
-static int tune_c2f_tiles(irmv_engine *e)
-{
-    const char *pin = getenv("IRMV_C2F_TILE");
-    const char *env = getenv("IRMV_AUTOTUNE");
-    const int counts[2] = {stream_share(e, e->cfg.num_slots), 1};
-    hipEvent_t ea, eb;
-    HIP_TRY(hipEventCreate(&ea));
-    HIP_TRY(hipEventCreate(&eb));
-    for (Op &op : e->ops) {
-        if (op.kind != OP_C2F32) continue;
-        for (int pass = 0; pass < 2; pass++) {
-            if (pin) { op.c2f_tile_h[pass] = atoi(pin) == 16 ? 16 : 8; continue; }
-            if (env && env[0] == '0') continue;
-            float best = 1e30f;
-            for (int th = 8; th <= 16; th *= 2) {
-                bool ok = true;
-                for (int i = 0; i < 2 && ok; i++) ok = launch_c2f32_op(e, op, 0, counts[pass], th, e->stream);
-                if (!ok) continue;
-                float ms = 1e30f;
-                for (int rep = 0; rep < 3; rep++) {
-                    HIP_TRY(hipEventRecord(ea, e->stream));
-                    for (int i = 0; i < 4; i++) launch_c2f32_op(e, op, 0, counts[pass], th, e->stream);
-                    HIP_TRY(hipEventRecord(eb, e->stream));
-                    HIP_TRY(hipEventSynchronize(eb));
-                    float t = 0.f;
-                    HIP_TRY(hipEventElapsedTime(&t, ea, eb));
-                    ms = t < ms ? t : ms;
-                }
-                if (getenv("IRMV_AUTOTUNE_VERBOSE")) fprintf(stderr, "[autotune] %-22s count=%-3d c2f32 tile %2d x 16  %8.2f us\n", op.layer.c_str(), counts[pass], th, ms / 4 * 1e3);
-                if (ms < best) { best = ms; op.c2f_tile_h[pass] = th; }
-            }
-        }
-        snprintf(op.kname, sizeof op.kname, "%s%s", op.mode == 0 ? "c2f32_ab" : (op.mode == 1 ? "c2f32_a" : "c2f32_b"), op.c2f_tile_h[0] == 16 ? "_t16" : "");
-    }
-    (void)hipEventDestroy(ea);
-    (void)hipEventDestroy(eb);
-    HIP_TRY(hipGetLastError());
-    return IRMV_OK;
 }
 
 static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bool post_only, std::vector<EvRec> *ev)
@@ -1874,8 +1829,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             break;
         }
         case OP_C2F32: {
-            const int th = op.c2f_tile_h[(count == 1 && stream_share(e, e->cfg.num_slots) > 1) ? 1 : 0];
-            if (!launch_c2f32_op(e, op, first, count, th, s)) return fail(IRMV_ERR_ARG, "no fused C2f kernel for " + op.layer);
+            if (!launch_c2f32_op(e, op, first, count, s)) return fail(IRMV_ERR_ARG, "no fused C2f kernel for " + op.layer);
             break;
         }
         case OP_DW: {

@@ -119,11 +119,10 @@ struct C2f32Args {
     half_t *out;          // block output [B][H][W][out_ld], 64 channels (modes 0, 2)
     int out_ld;
     int H, W, tiles_x, tiles_y;
-    int tile_h;           // 8 (four-wave workgroup) or 16 (eight waves, a third less halo work); tiles_y counts tiles of this height
     const half_t *w_cv1, *w_m1, *w_m2, *w_cv2;   // direct-family packings
     const float *b_cv1, *b_m1, *b_m2, *b_cv2;
 };
-size_t c2f32_lds_bytes(int mode, int tile_h = kC2f32TileH);
+size_t c2f32_lds_bytes(int mode);
 bool launch_c2f32(int mode, bool shortcut, const C2f32Args &a, int batch, hipStream_t s);
 
 struct ConvArgs {

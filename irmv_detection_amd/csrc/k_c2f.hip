@@ -254,17 +254,12 @@ void launch_c2f2(const C2fArgs &a, int batch, hipStream_t s)
 // (tests/test_gpu_engine.py::test_fused_kernels_are_bitwise_identical).
 // =====================================================================================================================
 namespace {
-constexpr int FW = kC2f32TileW;                              // output tile width; its height FH is 8 (four waves) or 16 (eight)
-constexpr int R1W = FW + 4, R2W = FW + 2;
+constexpr int FH = kC2f32TileH, FW = kC2f32TileW;       // output tile
+constexpr int R1H = FH + 4, R1W = FW + 4, R1N = R1H * R1W;   // y1 / bottleneck-input region (halo 2): 12 x 20 = 240 = 15 tiles
+constexpr int R2H = FH + 2, R2W = FW + 2, R2N = R2H * R2W;   // bottleneck intermediate (halo 1): 10 x 18 = 180
+constexpr int R3N = FH * FW;                                 // 128 = 8 tiles
 constexpr int PS = 96;                                       // bytes per pixel of a 32-channel plane
-// Regions of a tile of height FH: y1 / bottleneck input (halo 2): 12 x 20 = 15 MFMA tiles | 20 x 20 = 25; bottleneck
-// intermediate (halo 1): 10 x 18 = 180 pixels | 18 x 18 = 324; the tile itself: 8 | 16 MFMA tiles.  The taller tile runs
-// cv1 on 1.56 x instead of 1.88 x and m.cv1 on 1.27 x instead of 1.41 x the tile's pixels: 11 % fewer MFMAs and 10 % fewer
-// SiLUs per output pixel, for 118 KiB of LDS (one 8-wave workgroup per CU instead of two of four waves).
-constexpr int r1n(int fh) { return (fh + 4) * R1W; }
-constexpr int r2n(int fh) { return (fh + 2) * R2W; }
-constexpr int r3n(int fh) { return fh * FW; }
-static_assert(r1n(8) % 16 == 0 && r1n(16) % 16 == 0, "tile regions are whole MFMA tiles");
+static_assert(R1N % 16 == 0 && R3N % 16 == 0, "tile regions are whole MFMA tiles");
 }  // namespace
 
 #ifndef IRMV_EXP
@@ -279,12 +274,10 @@ __device__ unsigned long long g_c2f_phase[16];
 #else
 #define C2F_STAMP(k) do { } while (0)
 #endif
-// MODE 0 = AB, 1 = A, 2 = B.  KS1 = k-steps of cv1 (Cin / 32).  FH = tile height (8: four waves; 16: eight).
-template <int MODE, int KS1, bool SHORTCUT, int FH = 8>
-__global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
+// MODE 0 = AB, 1 = A, 2 = B.  KS1 = k-steps of cv1 (Cin / 32).
+template <int MODE, int KS1, bool SHORTCUT>
+__global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
 {
-    constexpr int NWV = FH / 2, NTHR = 64 * NWV;             // waves / threads of the workgroup
-    constexpr int R1N = r1n(FH), R2N = r2n(FH), R3N = r3n(FH);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_in = smem;                         // y1 region (modes AB, A) / y_prev region (mode B)
     uint8_t *s_t = s_in + R1N * PS;               // bottleneck intermediate
@@ -310,7 +303,7 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
 #endif
 
     u32x4 Y01[2][2];   // mode B only
-    static_assert(R3N / 16 == 2 * NWV, "two output tiles per wave");
+    static_assert(R3N / 16 == 8, "two output tiles per wave");
     if constexpr (MODE != 2) {
         // ---- 1: cv1 (1x1, Cin -> 64 = y0 | y1, SiLU) on the 12 x 20 region, B fragments straight from memory ----
         half8 W1[4][KS1];
@@ -345,7 +338,7 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
         };
         u32x4 Bn[KS1];
         load_tile(wave, Bn);
-        for (int t = wave; t < R1N / 16; t += NWV) {
+        for (int t = wave; t < R1N / 16; t += 4) {
             const int m = t * 16 + r;
             const int ly = m / R1W, lx = m - ly * R1W;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
@@ -353,7 +346,7 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
             half8 B[KS1];
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) B[ks] = as_h8(keep_if(inside, Bn[ks]));   // the select waits for the load: here, not at issue
-            if (t + NWV < R1N / 16) load_tile(t + NWV, Bn);
+            if (t + 4 < R1N / 16) load_tile(t + 4, Bn);
             f32x4 acc[4];
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -390,7 +383,7 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
         // kernel computes, and loaded where they are used each tile exposed a memory round trip
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const int m = (wave + NWV * i) * 16 + r;
+            const int m = (wave + 4 * i) * 16 + r;
             const int ly = m / FW, lx = m - ly * FW;
             const int gy = oy0 + ly, gx = ox0 + lx;
             const bool in = gy < H && gx < W;
@@ -400,11 +393,11 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
         }
         // ---- 1': the previous bottleneck's output (slice y_prev of the concat buffer) with a 2-pixel halo -> LDS ----
         const half_t *src = cat + a.prev_coff;
-        constexpr int NP = (R1N * 4 + NTHR - 1) / NTHR;   // 16-byte pieces per thread: all loads issued before the first LDS store
+        constexpr int NP = (R1N * 4 + 255) / 256;   // 16-byte pieces per thread: all loads issued before the first LDS store
         u32x4 v[NP];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            const int e = tid + i * NTHR;
+            const int e = tid + i * 256;
             const int m = e >> 2, q = e & 3;
             const int ly = m / R1W, lx = m - ly * R1W;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
@@ -413,7 +406,7 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
         }
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            const int e = tid + i * NTHR;
+            const int e = tid + i * 256;
             const int m = e >> 2;
             const int ly = m / R1W, lx = m - ly * R1W;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
@@ -435,7 +428,7 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
         float bias[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) bias[i] = s_bias[g * 8 + i];
-        for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : (R2N + 15) / 16); t += NWV) {
+        for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : (R2N + 15) / 16); t += 4) {
             const int m = t * 16 + r;
             const bool mv = m < R2N;
             const int mm = mv ? m : 0;
@@ -477,7 +470,7 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
         float bias[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) bias[i] = s_bias[32 + g * 8 + i];
-        for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : R3N / 16); t += NWV) {
+        for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : R3N / 16); t += 4) {
             const int m = t * 16 + r;
             const int ly = m / FW, lx = m - ly * FW;
             const uint8_t *base = s_t + (ly * R2W + lx) * PS + g * 16;
@@ -526,7 +519,7 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
 #pragma unroll
             for (int i = 0; i < 8; i++) bias[u * 8 + i] = s_bias[64 + u * 32 + g * 8 + i];
         half_t *out = a.out + (size_t)b * H * W * a.out_ld;
-        for (int t = wave; t < ((IRMV_ABL & 4) ? 0 : R3N / 16); t += NWV) {
+        for (int t = wave; t < ((IRMV_ABL & 4) ? 0 : R3N / 16); t += 4) {
             const int m = t * 16 + r;
             const int ly = m / FW, lx = m - ly * FW;
             const int gy = oy0 + ly, gx = ox0 + lx;
@@ -538,8 +531,8 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
                 B[2] = *reinterpret_cast<const half8 *>(s_yn + m * PS + g * 16);
             } else {
                 // y0, y1 are read once per pixel: straight from the concat buffer (at kernel start); y2 = the staged slice; y3 = this kernel's
-                B[0] = as_h8(keep_if(inside, Y01[(t - wave) / NWV][0]));
-                B[1] = as_h8(keep_if(inside, Y01[(t - wave) / NWV][1]));
+                B[0] = as_h8(keep_if(inside, Y01[(t - wave) >> 2][0]));
+                B[1] = as_h8(keep_if(inside, Y01[(t - wave) >> 2][1]));
                 B[2] = *reinterpret_cast<const half8 *>(s_in + ((ly + 2) * R1W + lx + 2) * PS + g * 16);
                 B[3] = *reinterpret_cast<const half8 *>(s_yn + m * PS + g * 16);
             }
@@ -576,35 +569,31 @@ __global__ __launch_bounds__(32 * FH) void c2f32_kernel(C2f32Args a)
 
 static std::mutex g_c2f_attr_mu;
 
-size_t c2f32_lds_bytes(int mode, int tile_h) { return (size_t)(r1n(tile_h) + r2n(tile_h) + (mode == 1 ? 0 : r3n(tile_h)) + (mode == 0 ? r3n(tile_h) : 0)) * PS; }
+size_t c2f32_lds_bytes(int mode) { return (size_t)(R1N + R2N + (mode == 1 ? 0 : R3N) + (mode == 0 ? R3N : 0)) * PS; }
 
-// a.tile_h = 8 or 16 (a.tiles_y counts tiles of that height)
 bool launch_c2f32(int mode, bool shortcut, const C2f32Args &a, int batch, hipStream_t s)
 {
     const int ks1 = a.cin1 / 32;
-    if (a.tile_h != 8 && a.tile_h != 16) return false;
-    const dim3 grid(a.tiles_x * a.tiles_y, batch), block(32 * a.tile_h);
-    const size_t lds = c2f32_lds_bytes(mode, a.tile_h);
-#define IRMV_C2F32_(MODE_, KS_, SC_, FH_)                                                                          \
-    if (mode == MODE_ && (MODE_ == 2 || ks1 == KS_) && shortcut == SC_ && a.tile_h == FH_) {                        \
+    const dim3 grid(a.tiles_x * a.tiles_y, batch), block(256);
+    const size_t lds = c2f32_lds_bytes(mode);
+#define IRMV_C2F32(MODE_, KS_, SC_)                                                                               \
+    if (mode == MODE_ && (MODE_ == 2 || ks1 == KS_) && shortcut == SC_) {                                          \
         static unsigned long long attr_done = 0;                                                                   \
         int dev = 0; (void)hipGetDevice(&dev);                                                                     \
         {   /* per device, once, and nobody launches before the limit is raised */                                 \
             std::lock_guard<std::mutex> lk(g_c2f_attr_mu);                                                         \
             if (!(attr_done & (1ull << (dev & 63)))) {                                                             \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(c2f32_kernel<MODE_, KS_, SC_, FH_>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(c2f32_kernel<MODE_, KS_, SC_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
                 attr_done |= 1ull << (dev & 63);                                                                   \
             }                                                                                                      \
         }                                                                                                          \
-        hipLaunchKernelGGL((c2f32_kernel<MODE_, KS_, SC_, FH_>), grid, block, lds, s, a);                          \
+        hipLaunchKernelGGL((c2f32_kernel<MODE_, KS_, SC_>), grid, block, lds, s, a);                               \
         return true;                                                                                               \
     }
-#define IRMV_C2F32(MODE_, KS_, SC_) IRMV_C2F32_(MODE_, KS_, SC_, 8) IRMV_C2F32_(MODE_, KS_, SC_, 16)
     IRMV_C2F32(0, 2, true) IRMV_C2F32(0, 2, false) IRMV_C2F32(0, 4, false) IRMV_C2F32(0, 6, false) IRMV_C2F32(0, 6, true) IRMV_C2F32(0, 4, true)
     IRMV_C2F32(1, 2, true) IRMV_C2F32(1, 2, false) IRMV_C2F32(1, 4, true) IRMV_C2F32(1, 6, true)
     IRMV_C2F32(2, 1, true) IRMV_C2F32(2, 1, false)
 #undef IRMV_C2F32
-#undef IRMV_C2F32_
     return false;
 }
 

@@ -22,7 +22,7 @@ def internal_name(sym):
         return f"conv1x1s1_pw_n{m.group(2)}"
     if "conv1x1_pw_kernel" in sym:
         return "conv1x1s1_pw"
-    m = re.search(r"c2f32_kernel<(\d), (\d), (true|false)>", sym)
+    m = re.search(r"c2f32_kernel<(\d), (\d), (true|false)(?:, \d+)?>", sym)
     if m:
         return {"0": "c2f32_ab", "1": "c2f32_a", "2": "c2f32_b"}[m.group(1)]
     for k, v in (("front_kernel", "front_fused"), ("c2f2_kernel", "c2f2_fused"), ("light_extract_kernel", "light_extract"), ("preprocess_kernel", "preprocess"), ("conv0_kernel", "conv0_mfma"), ("sppf_pool", "sppf_pool"), ("decode_kernel", "decode"), ("nms_pnp_kernel", "nms_pnp")):

@@ -35,7 +35,7 @@ int main(int argc, char **argv)
     a.cin1 = 192;
     a.cat = dev_half((size_t)B * S * S * 96, 1.f); a.cat_ld = 96; a.prev_coff = 64;
     a.out = dev_half((size_t)B * S * S * 64, 1.f); a.out_ld = 64;
-    a.H = a.W = S; a.tile_h = getenv("C2F_TILE") ? atoi(getenv("C2F_TILE")) : irmv::kC2f32TileH; a.tiles_x = S / irmv::kC2f32TileW; a.tiles_y = (S + a.tile_h - 1) / a.tile_h;
+    a.H = a.W = S; a.tiles_x = S / irmv::kC2f32TileW; a.tiles_y = S / irmv::kC2f32TileH;
     a.w_cv1 = dev_half(4 * 6 * 512, 0.1f); a.w_m1 = dev_half(2 * 9 * 512, 0.1f); a.w_m2 = dev_half(2 * 9 * 512, 0.1f); a.w_cv2 = dev_half(4 * 3 * 512, 0.1f);
     a.b_cv1 = dev_float(64); a.b_m1 = dev_float(32); a.b_m2 = dev_float(32); a.b_cv2 = dev_float(64);
     hipStream_t st; CK(hipStreamCreate(&st));

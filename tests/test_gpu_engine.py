@@ -546,28 +546,6 @@ def test_every_remaining_switch_is_bitwise_the_default(blob, monkeypatch, switch
             assert np.array_equal(a, b), switch
 
 
-@pytest.mark.parametrize("net", [640, 416])
-def test_fused_c2f_tile_heights_are_bitwise_identical(blob, monkeypatch, net):
-    """The fused 32-channel C2f kernels (model.4 as two launches, model.15) with 8 x 16 tiles (four waves) and 16 x 16 tiles
-    (eight waves, a third less halo work): same arithmetic per pixel -> same bits; at a 416 net the 52 x 52 map leaves partial
-    tiles in both directions."""
-    imgs = [frames.synthetic_frame(140 + i) for i in range(3)]
-    out = {}
-    for th in ("8", "16"):
-        monkeypatch.setenv("IRMV_C2F_TILE", th)
-        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3, num_streams=1, net_size=net) as e:
-            names = [st["name"] for st in e.profile(0, 3)]
-            assert (sum(n.endswith("_t16") for n in names) == 3) == (th == "16"), names
-            for s, im in enumerate(imgs):
-                _load(e, s, im)
-            e.submit(0, 3); e.wait()
-            out[th] = [e.read_head(s).copy() for s in range(3)] + [e.read_tap(t, 2).copy() for t in ("4", "15")]
-            e.detect(1)
-            out[th].append(e.read_head(1).copy())
-    for a, b in zip(out["8"], out["16"]):
-        assert np.array_equal(a, b)
-
-
 def test_eight_wave_tiles_on_maps_that_do_not_tile(blob, monkeypatch):
     """The stride-2 layers' 8-wave workgroup on a 416 net: 52 x 52, 26 x 26 and 13 x 13 outputs take the row-run block
     scheme (no 2-D block divides them), last blocks are partial, the batch's last image group is short (three frames)."""
