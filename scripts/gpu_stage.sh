@@ -78,7 +78,7 @@ traffic) cd /tmp; export TMPDIR=/tmp
 probe)   run probe_build 120 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 scripts/probes/stream_probe.cpp -o $O/stream_probe
          run stream_probe 200 $O/stream_probe ;;
 trace1)  cd /tmp; export TMPDIR=/tmp
-         TAG=trace run trace1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/scripts/lat_probe.py
+         TAG=trace run trace1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/scripts/probe.py lat
          cd $R
          python3 - <<PY > $O/trace1_summary.txt 2>&1
 import csv, glob, collections
@@ -98,21 +98,21 @@ for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:40]:
     print(f'{k:72s} n={len(v):5d} mean {statistics.mean(v)/1000:7.2f} us')
 PY
          cat $O/trace1_summary.txt | head -50 ;;
-hostprobe) run host_probe 500 python3 scripts/host_probe.py ;;
-hostprobe2) run host_probe_plain 300 python3 scripts/host_probe.py
-         PROBE_TORCH=1 run host_probe_torch 300 python3 scripts/host_probe.py
-         cp profiles/r01_tune_cache.txt $O/tc_probe.txt; IRMV_TUNE_CACHE=$O/tc_probe.txt run host_probe_cache 300 python3 scripts/host_probe.py ;;
+hostprobe) run host_probe 500 python3 scripts/probe.py host ;;
+hostprobe2) run host_probe_plain 300 python3 scripts/probe.py host
+         PROBE_TORCH=1 run host_probe_torch 300 python3 scripts/probe.py host
+         cp profiles/r01_tune_cache.txt $O/tc_probe.txt; IRMV_TUNE_CACHE=$O/tc_probe.txt run host_probe_cache 300 python3 scripts/probe.py host ;;
 crashprobe) cd /tmp; export TMPDIR=/tmp
          for v in inline nozc default; do
            case $v in default) E="";; inline) E="IRMV_INLINE_COPIES=1";; nozc) E="IRMV_ZERO_COPY_RESULTS=0";; esac
            echo "=== crashprobe $v" | tee -a $O/stages.log
-           env TAG=$v $E timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/crash_$v -- python3 $R/scripts/prof_crash_probe.py > $O/crash_$v.log 2>&1
+           env TAG=$v $E timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/crash_$v -- python3 $R/scripts/probe.py crash > $O/crash_$v.log 2>&1
            rc=$?; echo "=== crashprobe $v exit $rc" | tee -a $O/stages.log
            grep "^\[" $O/crash_$v.log
            if [ $rc -ge 124 ]; then echo "crashprobe $v died: stopping the chain" | tee -a $O/stages.log; exit $rc; fi
          done
          cd $R ;;
-s2probe) NET=416 run s2_probe 300 python3 scripts/s2_probe.py ;;
+s2probe) NET=416 run s2_probe 300 python3 scripts/probe.py s2 ;;
 pmc1x1)  cd /tmp; export TMPDIR=/tmp
          IRMV_STREAMS=1 run pmc_pw_a 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_pw_a -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
          IRMV_STREAMS=1 run pmc_pw_b 300 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_pw_b -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
@@ -138,13 +138,13 @@ abwaves) for w in 3 4; do
            SLOTS=64 TOP=60 run layers64_w$w 300 python3 scripts/prof_layers.py
          done
          run build_w2 600 python3 -c "from irmv_detection_amd import _build; import os; os.remove(_build.LIB_DIR + '/k_conv.o'); print(_build.build())" ;;
-tunev)   SLOTS=1 run tune_verbose 300 python3 scripts/tune_verbose.py ;;
-stamps)  TAG=stamps IRMV_NMS_STAMPS=1 run nms_stamps 200 python3 scripts/lat_probe.py ;;
-headerr) run head_error 400 python3 scripts/head_error.py ;;
-lat)     TAG=linear run lat_linear 200 python3 scripts/lat_probe.py ;;
+tunev)   SLOTS=1 run tune_verbose 300 python3 scripts/probe.py tune ;;
+stamps)  TAG=stamps IRMV_NMS_STAMPS=1 run nms_stamps 200 python3 scripts/probe.py lat ;;
+headerr) run head_error 400 python3 scripts/probe.py headerr ;;
+lat)     TAG=linear run lat_linear 200 python3 scripts/probe.py lat ;;
 repro)   # the round-1 fault sequence, ONCE, under the profiler that exposed it, with every allocation range logged
          cd /tmp; export TMPDIR=/tmp
-         IRMV_LOG_ALLOC=1 run repro_prof 300 rocprofv3 --kernel-trace --output-format csv -d $O/repro_prof -- python3 $R/scripts/repro_two_engines.py
+         IRMV_LOG_ALLOC=1 run repro_prof 300 rocprofv3 --kernel-trace --output-format csv -d $O/repro_prof -- python3 $R/scripts/probe.py repro
          cd $R ;;
 *)       run "custom_$st" 600 bash -c "$st" ;;
 esac
