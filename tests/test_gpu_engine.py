@@ -405,9 +405,11 @@ def test_tile_choice_is_bitwise_neutral(blob, frame0):
     assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2])
 
 
-def test_pointwise_kernel_is_bitwise_the_direct_kernel(blob, monkeypatch):
+@pytest.mark.parametrize("net", [640, 416])
+def test_pointwise_kernel_is_bitwise_the_direct_kernel(blob, monkeypatch, net):
     """The persistent 1x1 kernel (weights in LDS, pixel tiles software-pipelined; k_conv.hip) against the direct kernel it
-    may replace: same operands, same k order -> same bits, batched (partial last tiles included: 3 frames) and single-frame."""
+    may replace: same operands, same k order -> same bits, batched (partial last tiles included: 3 frames) and single-frame; at a 416 net the
+    26 x 26 and 13 x 13 maps leave odd numbers of 16-pixel units and partial units."""
     imgs = [frames.synthetic_frame(40 + i) for i in range(3)]
     heads = {}
     # IRMV_FORCE_PWN: the multi-block form (one 8-wave workgroup runs a pixel tile against 2 / 4 output-channel blocks whose
@@ -418,7 +420,7 @@ def test_pointwise_kernel_is_bitwise_the_direct_kernel(blob, monkeypatch):
         monkeypatch.setenv(mode, "1")
         if mode == "IRMV_FORCE_PW":
             monkeypatch.setenv("IRMV_NO_PWN", "1")
-        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3, num_streams=1) as e:
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3, num_streams=1, net_size=net) as e:
             names = [st["name"] for st in e.profile(0, 3)] + [st["name"] for st in e.profile(0, 1)]
             assert any(n == "conv1x1s1_pw" for n in names) == (mode == "IRMV_FORCE_PW"), (mode, names)
             assert (sum(n.startswith("conv1x1s1_pw_n") for n in names) >= 10) == (mode == "IRMV_FORCE_PWN"), (mode, names)
