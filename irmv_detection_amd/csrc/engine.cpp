@@ -237,7 +237,7 @@ struct irmv_engine {
     bool fused_front = false;          // OP_FRONT replaces preprocess + model.0.conv + model.1.conv in a step
     int front_tiles_x = 0, front_tiles_y = 0, front_stage_bytes = 0;
     int front_v[4] = {0, 0, 0, 0};     // valid (non-padding) net-input column / row ranges
-    int front_fastx = 0, front_fx_i0 = 0;   // every x tap is (i0 + 2 k, i0 + 2 k + 1; 1/2): the front kernel's 2 : 1 column path
+    int front_fastx = 0, front_fx_i0 = 0, front_fx_step = 2;   // every x tap is (i0 + 2 k, i0 + 2 k + 1; 1/2): the front kernel's 2 : 1 column path
     bool classical = false;            // four points from the classical light extraction instead of a keypoint head
     signed char *light_labels = nullptr;   // label pool: light_pool bytes per slot
     size_t light_pool = 0;
@@ -710,13 +710,18 @@ static int build_engine(irmv_engine *e)
     HIP_TRY(hipMemcpy(e->tap_y, ty.data(), net * sizeof(AxisTap), hipMemcpyHostToDevice));
     e->fused_front = front_fits(tx, ty, net, c.src_width, &e->front_tiles_x, &e->front_tiles_y, &e->front_stage_bytes);
     e->front_v[0] = px; e->front_v[1] = px + nw; e->front_v[2] = py; e->front_v[3] = py + nh;
-    {   // columns at exactly 2 : 1 (1280 -> 640): taps (i0 + 2 k, i0 + 2 k + 1), both weights 1/2, i0 even
-        bool fx = nw > 0 && tx[px].i0 >= 0 && (tx[px].i0 & 1) == 0;
+    {   // columns at exactly 2 : 1 (1280 -> 640): the taps of column px + k are the aligned source pair (m, m + 1) with
+        // m = m0 + step k even, both weights 1/2; step = 2, or -2 under rotate180 (the pair is then listed as (m + 1, m):
+        // with equal weights the blend does not care)
+        const int step = c.rotate180 ? -2 : 2;
+        const int m0 = nw > 0 ? std::min(tx[px].i0, tx[px].i1) : -1;
+        bool fx = nw > 0 && m0 >= 0 && (m0 & 1) == 0;
         for (int d = px; d < px + nw && fx; d++)
-            fx = tx[d].i0 == tx[px].i0 + 2 * (d - px) && tx[d].i1 == tx[d].i0 + 1 && tx[d].w1 == 1024;
+            fx = std::min(tx[d].i0, tx[d].i1) == m0 + step * (d - px) && std::max(tx[d].i0, tx[d].i1) == m0 + step * (d - px) + 1 && tx[d].w1 == 1024;
         if (const char *f = getenv("IRMV_FRONT_FASTX")) if (f[0] == '0') fx = false;
         e->front_fastx = fx ? 1 : 0;
-        e->front_fx_i0 = fx ? tx[px].i0 : 0;
+        e->front_fx_i0 = fx ? m0 : 0;
+        e->front_fx_step = step;
     }
     if (const char *ff = getenv("IRMV_FUSED_FRONT")) if (ff[0] == '0') e->fused_front = false;
     if (e->fused_front && !front_prepare()) e->fused_front = false;
@@ -1805,7 +1810,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             a.tx = e->tap_x; a.ty = e->tap_y;
             a.vx0 = e->front_v[0]; a.vx1 = e->front_v[1]; a.vy0 = e->front_v[2]; a.vy1 = e->front_v[3];
             a.sw = e->cfg.src_width; a.sh = e->cfg.src_height; a.net = net; a.swap_rb = e->cfg.swap_rb;
-            a.fastx = e->front_fastx; a.fx_i0 = e->front_fx_i0;
+            a.fastx = e->front_fastx; a.fx_i0 = e->front_fx_i0; a.fx_step = e->front_fx_step;
             a.w0 = e->conv0_w; a.b0 = e->conv0_b;
             a.w1 = op.w_packed; a.b1 = op.bias;
             const Tensor &ot = e->tensors[op.out_t];

@@ -191,9 +191,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
             // of a channel is 1024 (p0 + p1), so with s = p0 + p1 of the two tap rows the fixed-point result
             // ((2048 - wy) 1024 s0 + wy 1024 s1 + 2^21) >> 22 is ((2048 - wy) s0 + wy s1 + 2^11) >> 12 -- the same integer.
             // The pair of a row is one aligned 8-byte LDS read; red / blue are summed side by side in one register.
-            const int xbase = a.fx_i0 + 2 * (gx0 - a.vx0) - x0;   // region-relative tap of lx = 0 (even: x0 and fx_i0 are)
+            const int xbase = a.fx_i0 + a.fx_step * (gx0 - a.vx0) - x0;   // region-relative pair of lx = 0 (even: x0 and fx_i0 are)
+            const int xstep = a.fx_step;                                   // -2 under rotate180
             auto blend = [&](int ly, int lx, uint32_t ty) -> half4 {
-                const int xa = xbase + 2 * lx;
+                const int xa = xbase + xstep * lx;
                 const uint2 q0 = *reinterpret_cast<const uint2 *>(s_px + __umul24(ty & 1023u, pitch) + xa);
                 const uint2 q1 = *reinterpret_cast<const uint2 *>(s_px + __umul24((ty >> 10) & 1023u, pitch) + xa);
                 const uint32_t wy = ty >> 20, wy0 = kCoefOne - wy;
