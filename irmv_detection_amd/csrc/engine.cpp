@@ -719,7 +719,9 @@ static int build_engine(irmv_engine *e)
         for (int d = px; d < px + nw && fx; d++)
             fx = std::min(tx[d].i0, tx[d].i1) == m0 + step * (d - px) && std::max(tx[d].i0, tx[d].i1) == m0 + step * (d - px) + 1 && tx[d].w1 == 1024;
         if (const char *f = getenv("IRMV_FRONT_FASTX")) if (f[0] == '0') fx = false;
-        e->front_fastx = fx ? 1 : 0;
+        bool direct = fx;   // tiles without a padding pixel skip the LDS staging of the source (k_front.hip); bit 1 of FrontArgs::fastx
+        if (const char *f = getenv("IRMV_FRONT_DIRECT")) if (f[0] == '0') direct = false;
+        e->front_fastx = fx ? (direct ? 3 : 1) : 0;
         e->front_fx_i0 = fx ? m0 : 0;
         e->front_fx_step = step;
     }

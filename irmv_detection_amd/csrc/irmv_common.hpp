@@ -53,7 +53,7 @@ struct FrontArgs {
     const AxisTap *tx, *ty;
     int vx0, vx1, vy0, vy1;   // net-input columns / rows with a source tap: [v0, v1) (the rest is letterbox padding)
     int sw, sh, net, swap_rb;
-    int fastx, fx_i0, fx_step;   // columns at exactly 2 : 1: column vx0 + k blends the source pair (m, m + 1), m = fx_i0 + fx_step k (fx_step = +-2), weights 1/2
+    int fastx, fx_i0, fx_step;   // columns at exactly 2 : 1: column vx0 + k blends the source pair (m, m + 1), m = fx_i0 + fx_step k (fx_step = +-2), weights 1/2; fastx bit 1: tiles without padding read the source straight into registers
     const half_t *w0;     // model.0.conv fragments (Conv0Args::w)
     const float *b0;
     const half_t *w1;     // model.1.conv, direct-family packing (Cin = 16: 5 k-steps x 2 paired tiles)

@@ -79,194 +79,271 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
     const half8 *wp0 = reinterpret_cast<const half8 *>(a.w0) + lane;
     const half8 A00 = wp0[0], A01 = wp0[64];
 
-    // ---- 0: bounding box of the source pixels the tile touches.  The tap tables are monotonic, so the box follows
-    // from the taps of the first and last in-image row / column of the tile (uniform addresses: scalar loads), and the
-    // source loads of A1 can be issued at once instead of behind a table read and a reduction.
-    const int cx_lo = max(gx0, a.vx0), cx_hi = min(gx0 + INW, a.vx1) - 1;
-    const int cy_lo = max(gy0, a.vy0), cy_hi = min(gy0 + INH, a.vy1) - 1;
-    const bool any_src = cx_lo <= cx_hi && cy_lo <= cy_hi;
-    int x0 = 0, x1 = 0, sy_min = 0, sy_max = -1;
-    if (any_src) {
-        const AxisTap xa = a.tx[cx_lo], xb = a.tx[cx_hi], ya = a.ty[cy_lo], yb = a.ty[cy_hi];
-        // (min3 / max3 exist on the vector unit only: back to scalar registers, or everything derived from the box --
-        // the region's base address, its group count, the walk's steps -- is computed per lane)
-        x0 = __builtin_amdgcn_readfirstlane(min(min(xa.i0, xa.i1), min(xb.i0, xb.i1)) & ~3);   // the region starts on a 4-pixel (12-byte) group
-        x1 = __builtin_amdgcn_readfirstlane(min((max(max(xa.i0, xa.i1), max(xb.i0, xb.i1)) + 4) & ~3, a.sw));
-        sy_min = __builtin_amdgcn_readfirstlane(min(min(ya.i0, ya.i1), min(yb.i0, yb.i1)));
-        sy_max = __builtin_amdgcn_readfirstlane(max(max(ya.i0, ya.i1), max(yb.i0, yb.i1)));
+    // ---- direct tiles (round 3): columns at exactly 2 : 1 and no padding pixel anywhere in the tile.  Every source pixel
+    // of such a tile feeds exactly one net-input pixel of it in x, so staging the region in LDS first (A1: 12-byte groups
+    // -> 4-byte pixels, a barrier, then A2's reads) is pure overhead: a thread loads the 12 bytes = two aligned source
+    // pairs of TWO tap rows straight into registers and blends two adjacent net-input pixels from them.  Same integers as
+    // A2's 2 : 1 path (sum of the pair, vertical blend, one rounding shift), so the same bits.
+    const bool tile_inside = gx0 >= max(a.vx0, 0) && gx0 + INW <= min(a.vx1, net) && gy0 >= max(a.vy0, 0) && gy0 + INH <= min(a.vy1, net);
+    bool direct = false;
+    int dg0 = 0, de = 0;
+    if ((a.fastx & 2) && tile_inside) {
+        const int mq = a.fx_i0 + a.fx_step * (gx0 - a.vx0);                       // source pair of the tile's first column
+        // a 12-byte group = source pixels g .. g + 3 (g a multiple of 4) = the pairs of two adjacent columns; the tile's
+        // columns are paired from column -de on so that every pair of columns is one such group
+        de = a.fx_step > 0 ? ((mq & 3) == 0 ? 0 : 1) : ((mq & 3) == 2 ? 0 : 1);
+        direct = de ? (gx0 - 1 >= a.vx0) : (gx0 + INW < a.vx1);                   // the one column outside the tile must have a source too
+        dg0 = a.fx_step > 0 ? mq - 2 * de : mq + 2 * de - 2;                        // group of the first pair of columns
     }
-    const int pitch = x1 - x0;                                       // staged pixels per row (4 bytes each)
-    // this lane's tap (lanes 0 .. INW + INH - 1: one column or row of the tile each); packed and stored behind the source loads
-    // (loaded by EVERY lane from a clamped index and masked where it is used: a load under a branch is copied out of the
-    // branch's block behind a wait -- for every load issued so far -- in front of the source loads)
-    const bool tap_x = tid < INW;
-    const int tap_i = tap_x ? gx0 + tid : gy0 + (tid - INW);
-    const bool tap_ok = tid < INW + INH && (unsigned)tap_i < (unsigned)net;
-    AxisTap my_tap = (tap_x ? a.tx : a.ty)[min(max(tap_i, 0), net - 1)];
-
-    FSTAMP(1);
-    // ---- A1: source region -> LDS as 4-byte pixels (12 source bytes -> one 16-byte LDS store) ----
-    uint32_t *s_px = reinterpret_cast<uint32_t *>(s_stage);
-    if (any_src) {
-        const size_t row_bytes = (size_t)a.sw * 3;
-        const uint8_t *src = a.src + (size_t)b * a.src_slot_bytes + (size_t)sy_min * row_bytes + (size_t)x0 * 3;
-        const int gpr = pitch >> 2, total = (sy_max - sy_min + 1) * gpr;
-        // All loads of a pass are issued before its first LDS store: a thread owns ~5 groups of the reference geometry
-        // (33 rows x 35 groups / 256 threads), and one group per loop trip meant ~5 exposed memory round trips per
-        // workgroup -- of a ~10 us workgroup lifetime.  CH = 6 groups per pass: one round trip for 1280 x 1024 -> 640.
-        // The kernel is bound by its vector-instruction issue (profiles/r02_mfma.json: VALU busy ~100 %), so the walk
-        // costs no division per group: group i sits at LDS dword 4 i and at source byte row(i) * skip + 12 i, and
-        // row(i + 256) follows from row(i) with one compare.
-        constexpr int CH = 6;
-        const float inv_gpr = __builtin_amdgcn_rcpf((float)gpr);   // (1 ulp: the correction steps below absorb it)
-        int dq = (int)(256.0f * inv_gpr);                         // 256 = dq * gpr + dr (uniform)
-        dq -= (dq * gpr > 256) ? 1 : 0;
-        dq += ((dq + 1) * gpr <= 256) ? 1 : 0;
-        dq = __builtin_amdgcn_readfirstlane(dq);
-        const int dr = 256 - dq * gpr;
-        int row = (int)((float)tid * inv_gpr);                    // tid < 2^15: one correction step makes the quotient exact
-        row -= (__mul24(row, gpr) > tid) ? 1 : 0;
-        row += (__mul24(row + 1, gpr) <= tid) ? 1 : 0;
-        int col = tid - __mul24(row, gpr);
-        const uint32_t skip = (uint32_t)(row_bytes - (size_t)gpr * 12);   // < 2^24 (the source is at most 4096 pixels wide)
-        const uint32_t off_last = (uint32_t)(sy_max - sy_min) * skip + (uint32_t)(total - 1) * 12u;
-        uint32_t d0[CH], d1[CH], d2[CH];
-        auto load_pass = [&](int i0) {
+    if (direct) {
+        constexpr int NPAIR = (INW + 1) / 2, NIT = INH * NPAIR;                    // 34 pairs x 19 rows = 646 items: three trips
+        static_assert(NPAIR == 34 && NIT > 512 && NIT <= 768, "the walk below is written for the 19 x 67 tile");
+        const uint8_t *srcb = a.src + (size_t)b * a.src_slot_bytes;
+        const uint32_t row_bytes = (uint32_t)a.sw * 3u;
+        const int sgn12 = a.fx_step > 0 ? 12 : -12;
+        int row = tid / NPAIR, p = tid - row * NPAIR;
+        int rowv[3], pv[3];
+        AxisTap tp[3];
 #pragma unroll
-            for (int c = 0; c < CH; c++) {
-                const int i = i0 + c * 256 + tid;
-                // (unconditional, past the end the region's last group again: loads under a branch are waited for one by one)
-                const uint32_t off = i < total ? __umul24((uint32_t)row, skip) + __umul24((uint32_t)i, 12u) : off_last;
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(src + off);
-                d0[c] = q[0]; d1[c] = q[1]; d2[c] = q[2];
-                col += dr; row += dq;
-                if (col >= gpr) { col -= gpr; row++; }
-            }
-        };
-        auto store_pass = [&](int i0) {
-#pragma unroll
-            for (int c = 0; c < CH; c++) {
-                const int i = i0 + c * 256 + tid;
-                if (i < total) {
-                    uint4 o;
-                    o.x = d0[c] & 0xffffffu;
-                    o.y = (d0[c] >> 24) | ((d1[c] & 0xffffu) << 8);
-                    o.z = (d1[c] >> 16) | ((d2[c] & 0xffu) << 16);
-                    o.w = d2[c] >> 8;
-                    *reinterpret_cast<uint4 *>(s_px + 4 * i) = o;
-                }
-            }
-        };
-        // the first pass in straight-line code: at a loop header the compiler waits for (nearly) every load in flight --
-        // the weights -- before the pass's own loads are issued
-        load_pass(0);
-        store_pass(0);
-        for (int i0 = 256 * CH; i0 < total; i0 += 256 * CH) {
-            load_pass(i0);
-            store_pass(i0);
+        for (int k = 0; k < 3; k++) {
+            rowv[k] = row; pv[k] = p;
+            tp[k] = a.ty[gy0 + min(row, INH - 1)];                                  // (the third trip's idle lanes: the last row again)
+            p += 256 - 7 * NPAIR; row += 7;
+            if (p >= NPAIR) { p -= NPAIR; row++; }
         }
-    }
-    // taps relative to the region, one dword each: i0 | i1 << 10 | w << 20 (w <= 2048); all ones = outside / padding.
-    // (The empty asm pins the first use of the loaded tap HERE: the compiler otherwise starts packing it right behind its
-    // load, and the wait that takes -- for every load issued so far -- lands in front of the source loads.)
-    asm volatile("" : "+v"(my_tap.i0), "+v"(my_tap.i1), "+v"(my_tap.w1));
-    if (tid < INW + INH) {
-        const int base = tap_x ? x0 : sy_min;
-        const uint32_t pk = (!tap_ok || my_tap.i0 < 0) ? 0xffffffffu : (uint32_t)(my_tap.i0 - base) | ((uint32_t)(my_tap.i1 - base) << 10) | ((uint32_t)my_tap.w1 << 20);
-        if (tap_x) s_tx[tid] = pk; else s_ty[tid - INW] = pk;
-    }
-    if (tid < 48) s_bias[tid] = bias_v;
-    FSTAMP(2);
-    __syncthreads();
-    FSTAMP(3);
-
-    // ---- A2: bilinear resample into the NHWC4 tile (arithmetic of preprocess_kernel) ----
-    {
-        const half_t padv = (half_t)(114.0f / 255.0f);
-        const float inv255 = 1.0f / 255.0f;   // (half)(q * inv255) == (half)(q / 255.0f) for every q in 0..255 (tests/test_oracle_preprocess.py)
-        if (tid < INH) s_in[tid * INP + INW] = (half4){0, 0, 0, 0};   // the extra column of every row stays zero
-        // 19 x 67 = 1273 pixels = five trips of 256 lanes (walking the padded 19 x 68 grid would need a sixth for 12 pixels)
-        if (a.fastx) {
-            // Columns at exactly 2 : 1 (every x tap = (2 k, 2 k + 1) with weight 1/2: 1280 -> 640): the horizontal blend
-            // of a channel is 1024 (p0 + p1), so with s = p0 + p1 of the two tap rows the fixed-point result
-            // ((2048 - wy) 1024 s0 + wy 1024 s1 + 2^21) >> 22 is ((2048 - wy) s0 + wy s1 + 2^11) >> 12 -- the same integer.
-            // The pair of a row is one aligned 8-byte LDS read; red / blue are summed side by side in one register.
-            const int xbase = a.fx_i0 + a.fx_step * (gx0 - a.vx0) - x0;   // region-relative pair of lx = 0 (even: x0 and fx_i0 are)
-            const int xstep = a.fx_step;                                   // -2 under rotate180
-            auto blend = [&](int ly, int lx, uint32_t ty) -> half4 {
-                const int xa = xbase + xstep * lx;
-                const uint2 q0 = *reinterpret_cast<const uint2 *>(s_px + __umul24(ty & 1023u, pitch) + xa);
-                const uint2 q1 = *reinterpret_cast<const uint2 *>(s_px + __umul24((ty >> 10) & 1023u, pitch) + xa);
-                const uint32_t wy = ty >> 20, wy0 = kCoefOne - wy;
-                const uint32_t rb0 = (q0.x & 0x00ff00ffu) + (q0.y & 0x00ff00ffu), rb1 = (q1.x & 0x00ff00ffu) + (q1.y & 0x00ff00ffu);
-                const uint32_t g0 = ((q0.x >> 8) & 255u) + ((q0.y >> 8) & 255u), g1 = ((q1.x >> 8) & 255u) + ((q1.y >> 8) & 255u);
-                const uint32_t rnd = 1u << (kCoefBits);
+        uint32_t dd[3][6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t xo = (uint32_t)(3 * dg0 + sgn12 * pv[k]);
+            const uint32_t *q0 = reinterpret_cast<const uint32_t *>(srcb + (uint32_t)tp[k].i0 * row_bytes + xo);
+            const uint32_t *q1 = reinterpret_cast<const uint32_t *>(srcb + (uint32_t)tp[k].i1 * row_bytes + xo);
+            dd[k][0] = q0[0]; dd[k][1] = q0[1]; dd[k][2] = q0[2];
+            dd[k][3] = q1[0]; dd[k][4] = q1[1]; dd[k][5] = q1[2];
+        }
+        if (tid < 48) s_bias[tid] = bias_v;
+        if (tid < INH) s_in[tid * INP + INW] = (half4){0, 0, 0, 0};               // the extra column of every row stays zero
+        FSTAMP(1); FSTAMP(2); FSTAMP(3);
+        const float inv255 = 1.0f / 255.0f;
+        const uint32_t rnd = 1u << kCoefBits;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (k == 2 && tid >= NIT - 512) break;
+            const uint32_t wy = (uint32_t)tp[k].w1, wy0 = kCoefOne - wy;
+            // bytes of a row's group: pixel 0 = b0 b1 b2, 1 = b3 b4 b5, 2 = b6 b7 b8, 3 = b9 b10 b11; first half = pixels 0 + 1
+            uint32_t rb[2][2], gg[2][2];   // [tap row][half]: channel 0 and 2 sums side by side, channel 1 sum
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const uint32_t d0 = dd[k][3 * t], d1 = dd[k][3 * t + 1], d2 = dd[k][3 * t + 2];
+                rb[t][0] = (d0 & 0x00ff00ffu) + __builtin_amdgcn_perm(d1, d0, 0x0c050c03u);            // (b0, b2) + (b3, b5)
+                gg[t][0] = ((d0 >> 8) & 255u) + (d1 & 255u);                                             // b1 + b4
+                rb[t][1] = __builtin_amdgcn_perm(d2, d1, 0x0c040c02u) + ((d2 >> 8) & 0x00ff00ffu);      // (b6, b8) + (b9, b11)
+                gg[t][1] = (d1 >> 24) + ((d2 >> 16) & 255u);                                             // b7 + b10
+            }
+            const int lxa = 2 * pv[k] - de;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {   // column lxa + h: the first half of the group under step +2, the second under -2
+                const int hs = a.fx_step > 0 ? h : 1 - h;
+                const uint32_t rb0 = hs ? rb[0][1] : rb[0][0], rb1 = hs ? rb[1][1] : rb[1][0];
+                const uint32_t g0v = hs ? gg[0][1] : gg[0][0], g1v = hs ? gg[1][1] : gg[1][0];
                 const uint32_t c0 = (__umul24(wy0, rb0 & 0xffffu) + __umul24(wy, rb1 & 0xffffu) + rnd) >> (kCoefBits + 1);
-                const uint32_t c1 = (__umul24(wy0, g0) + __umul24(wy, g1) + rnd) >> (kCoefBits + 1);
+                const uint32_t c1 = (__umul24(wy0, g0v) + __umul24(wy, g1v) + rnd) >> (kCoefBits + 1);
                 const uint32_t c2 = (__umul24(wy0, rb0 >> 16) + __umul24(wy, rb1 >> 16) + rnd) >> (kCoefBits + 1);
                 half_t v0 = (half_t)((float)c0 * inv255), v1 = (half_t)((float)c1 * inv255), v2 = (half_t)((float)c2 * inv255);
                 if (a.swap_rb) { const half_t t = v0; v0 = v2; v2 = t; }
-                return (half4){v0, v1, v2, (half_t)0.0f};
+                const int lx = lxa + h;
+                if ((unsigned)lx < (unsigned)INW) s_in[rowv[k] * INP + lx] = (half4){v0, v1, v2, (half_t)0.0f};
+            }
+        }
+    } else {
+    // ---- 0: bounding box of the source pixels the tile touches.  The tap tables are monotonic, so the box follows
+        // from the taps of the first and last in-image row / column of the tile (uniform addresses: scalar loads), and the
+        // source loads of A1 can be issued at once instead of behind a table read and a reduction.
+        const int cx_lo = max(gx0, a.vx0), cx_hi = min(gx0 + INW, a.vx1) - 1;
+        const int cy_lo = max(gy0, a.vy0), cy_hi = min(gy0 + INH, a.vy1) - 1;
+        const bool any_src = cx_lo <= cx_hi && cy_lo <= cy_hi;
+        int x0 = 0, x1 = 0, sy_min = 0, sy_max = -1;
+        if (any_src) {
+            const AxisTap xa = a.tx[cx_lo], xb = a.tx[cx_hi], ya = a.ty[cy_lo], yb = a.ty[cy_hi];
+            // (min3 / max3 exist on the vector unit only: back to scalar registers, or everything derived from the box --
+            // the region's base address, its group count, the walk's steps -- is computed per lane)
+            x0 = __builtin_amdgcn_readfirstlane(min(min(xa.i0, xa.i1), min(xb.i0, xb.i1)) & ~3);   // the region starts on a 4-pixel (12-byte) group
+            x1 = __builtin_amdgcn_readfirstlane(min((max(max(xa.i0, xa.i1), max(xb.i0, xb.i1)) + 4) & ~3, a.sw));
+            sy_min = __builtin_amdgcn_readfirstlane(min(min(ya.i0, ya.i1), min(yb.i0, yb.i1)));
+            sy_max = __builtin_amdgcn_readfirstlane(max(max(ya.i0, ya.i1), max(yb.i0, yb.i1)));
+        }
+        const int pitch = x1 - x0;                                       // staged pixels per row (4 bytes each)
+        // this lane's tap (lanes 0 .. INW + INH - 1: one column or row of the tile each); packed and stored behind the source loads
+        // (loaded by EVERY lane from a clamped index and masked where it is used: a load under a branch is copied out of the
+        // branch's block behind a wait -- for every load issued so far -- in front of the source loads)
+        const bool tap_x = tid < INW;
+        const int tap_i = tap_x ? gx0 + tid : gy0 + (tid - INW);
+        const bool tap_ok = tid < INW + INH && (unsigned)tap_i < (unsigned)net;
+        AxisTap my_tap = (tap_x ? a.tx : a.ty)[min(max(tap_i, 0), net - 1)];
+    
+        FSTAMP(1);
+        // ---- A1: source region -> LDS as 4-byte pixels (12 source bytes -> one 16-byte LDS store) ----
+        uint32_t *s_px = reinterpret_cast<uint32_t *>(s_stage);
+        if (any_src) {
+            const size_t row_bytes = (size_t)a.sw * 3;
+            const uint8_t *src = a.src + (size_t)b * a.src_slot_bytes + (size_t)sy_min * row_bytes + (size_t)x0 * 3;
+            const int gpr = pitch >> 2, total = (sy_max - sy_min + 1) * gpr;
+            // All loads of a pass are issued before its first LDS store: a thread owns ~5 groups of the reference geometry
+            // (33 rows x 35 groups / 256 threads), and one group per loop trip meant ~5 exposed memory round trips per
+            // workgroup -- of a ~10 us workgroup lifetime.  CH = 6 groups per pass: one round trip for 1280 x 1024 -> 640.
+            // The kernel is bound by its vector-instruction issue (profiles/r02_mfma.json: VALU busy ~100 %), so the walk
+            // costs no division per group: group i sits at LDS dword 4 i and at source byte row(i) * skip + 12 i, and
+            // row(i + 256) follows from row(i) with one compare.
+            constexpr int CH = 6;
+            const float inv_gpr = __builtin_amdgcn_rcpf((float)gpr);   // (1 ulp: the correction steps below absorb it)
+            int dq = (int)(256.0f * inv_gpr);                         // 256 = dq * gpr + dr (uniform)
+            dq -= (dq * gpr > 256) ? 1 : 0;
+            dq += ((dq + 1) * gpr <= 256) ? 1 : 0;
+            dq = __builtin_amdgcn_readfirstlane(dq);
+            const int dr = 256 - dq * gpr;
+            int row = (int)((float)tid * inv_gpr);                    // tid < 2^15: one correction step makes the quotient exact
+            row -= (__mul24(row, gpr) > tid) ? 1 : 0;
+            row += (__mul24(row + 1, gpr) <= tid) ? 1 : 0;
+            int col = tid - __mul24(row, gpr);
+            const uint32_t skip = (uint32_t)(row_bytes - (size_t)gpr * 12);   // < 2^24 (the source is at most 4096 pixels wide)
+            const uint32_t off_last = (uint32_t)(sy_max - sy_min) * skip + (uint32_t)(total - 1) * 12u;
+            uint32_t d0[CH], d1[CH], d2[CH];
+            auto load_pass = [&](int i0) {
+    #pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    const int i = i0 + c * 256 + tid;
+                    // (unconditional, past the end the region's last group again: loads under a branch are waited for one by one)
+                    const uint32_t off = i < total ? __umul24((uint32_t)row, skip) + __umul24((uint32_t)i, 12u) : off_last;
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(src + off);
+                    d0[c] = q[0]; d1[c] = q[1]; d2[c] = q[2];
+                    col += dr; row += dq;
+                    if (col >= gpr) { col -= gpr; row++; }
+                }
             };
-            // pixel tid + 256 k sits 3 rows and 55 columns (256 = 3 INW + 55) past pixel tid + 256 (k - 1)
-            static_assert(INW == 67 && INH * INW <= 5 * 256, "the walk below is written for the 19 x 67 tile");
-            int ly = tid / INW, lx = tid - ly * INW;
-            const bool inside = gx0 >= max(a.vx0, 0) && gx0 + INW <= min(a.vx1, net) && gy0 >= max(a.vy0, 0) && gy0 + INH <= min(a.vy1, net);
-            if (inside) {   // (three tiles in four) every pixel of the tile has both taps: nothing to test per pixel
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    if (k < 4 || tid < INH * INW - 4 * 256) s_in[ly * INP + lx] = blend(ly, lx, s_ty[ly]);
-                    lx += 256 - 3 * INW; ly += 3;
-                    if (lx >= INW) { lx -= INW; ly++; }
+            auto store_pass = [&](int i0) {
+    #pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    const int i = i0 + c * 256 + tid;
+                    if (i < total) {
+                        uint4 o;
+                        o.x = d0[c] & 0xffffffu;
+                        o.y = (d0[c] >> 24) | ((d1[c] & 0xffffu) << 8);
+                        o.z = (d1[c] >> 16) | ((d2[c] & 0xffu) << 16);
+                        o.w = d2[c] >> 8;
+                        *reinterpret_cast<uint4 *>(s_px + 4 * i) = o;
+                    }
+                }
+            };
+            // the first pass in straight-line code: at a loop header the compiler waits for (nearly) every load in flight --
+            // the weights -- before the pass's own loads are issued
+            load_pass(0);
+            store_pass(0);
+            for (int i0 = 256 * CH; i0 < total; i0 += 256 * CH) {
+                load_pass(i0);
+                store_pass(i0);
+            }
+        }
+        // taps relative to the region, one dword each: i0 | i1 << 10 | w << 20 (w <= 2048); all ones = outside / padding.
+        // (The empty asm pins the first use of the loaded tap HERE: the compiler otherwise starts packing it right behind its
+        // load, and the wait that takes -- for every load issued so far -- lands in front of the source loads.)
+        asm volatile("" : "+v"(my_tap.i0), "+v"(my_tap.i1), "+v"(my_tap.w1));
+        if (tid < INW + INH) {
+            const int base = tap_x ? x0 : sy_min;
+            const uint32_t pk = (!tap_ok || my_tap.i0 < 0) ? 0xffffffffu : (uint32_t)(my_tap.i0 - base) | ((uint32_t)(my_tap.i1 - base) << 10) | ((uint32_t)my_tap.w1 << 20);
+            if (tap_x) s_tx[tid] = pk; else s_ty[tid - INW] = pk;
+        }
+        if (tid < 48) s_bias[tid] = bias_v;
+        FSTAMP(2);
+        __syncthreads();
+        FSTAMP(3);
+    
+        // ---- A2: bilinear resample into the NHWC4 tile (arithmetic of preprocess_kernel) ----
+        {
+            const half_t padv = (half_t)(114.0f / 255.0f);
+            const float inv255 = 1.0f / 255.0f;   // (half)(q * inv255) == (half)(q / 255.0f) for every q in 0..255 (tests/test_oracle_preprocess.py)
+            if (tid < INH) s_in[tid * INP + INW] = (half4){0, 0, 0, 0};   // the extra column of every row stays zero
+            // 19 x 67 = 1273 pixels = five trips of 256 lanes (walking the padded 19 x 68 grid would need a sixth for 12 pixels)
+            if (a.fastx) {
+                // Columns at exactly 2 : 1 (every x tap = (2 k, 2 k + 1) with weight 1/2: 1280 -> 640): the horizontal blend
+                // of a channel is 1024 (p0 + p1), so with s = p0 + p1 of the two tap rows the fixed-point result
+                // ((2048 - wy) 1024 s0 + wy 1024 s1 + 2^21) >> 22 is ((2048 - wy) s0 + wy s1 + 2^11) >> 12 -- the same integer.
+                // The pair of a row is one aligned 8-byte LDS read; red / blue are summed side by side in one register.
+                const int xbase = a.fx_i0 + a.fx_step * (gx0 - a.vx0) - x0;   // region-relative pair of lx = 0 (even: x0 and fx_i0 are)
+                const int xstep = a.fx_step;                                   // -2 under rotate180
+                auto blend = [&](int ly, int lx, uint32_t ty) -> half4 {
+                    const int xa = xbase + xstep * lx;
+                    const uint2 q0 = *reinterpret_cast<const uint2 *>(s_px + __umul24(ty & 1023u, pitch) + xa);
+                    const uint2 q1 = *reinterpret_cast<const uint2 *>(s_px + __umul24((ty >> 10) & 1023u, pitch) + xa);
+                    const uint32_t wy = ty >> 20, wy0 = kCoefOne - wy;
+                    const uint32_t rb0 = (q0.x & 0x00ff00ffu) + (q0.y & 0x00ff00ffu), rb1 = (q1.x & 0x00ff00ffu) + (q1.y & 0x00ff00ffu);
+                    const uint32_t g0 = ((q0.x >> 8) & 255u) + ((q0.y >> 8) & 255u), g1 = ((q1.x >> 8) & 255u) + ((q1.y >> 8) & 255u);
+                    const uint32_t rnd = 1u << (kCoefBits);
+                    const uint32_t c0 = (__umul24(wy0, rb0 & 0xffffu) + __umul24(wy, rb1 & 0xffffu) + rnd) >> (kCoefBits + 1);
+                    const uint32_t c1 = (__umul24(wy0, g0) + __umul24(wy, g1) + rnd) >> (kCoefBits + 1);
+                    const uint32_t c2 = (__umul24(wy0, rb0 >> 16) + __umul24(wy, rb1 >> 16) + rnd) >> (kCoefBits + 1);
+                    half_t v0 = (half_t)((float)c0 * inv255), v1 = (half_t)((float)c1 * inv255), v2 = (half_t)((float)c2 * inv255);
+                    if (a.swap_rb) { const half_t t = v0; v0 = v2; v2 = t; }
+                    return (half4){v0, v1, v2, (half_t)0.0f};
+                };
+                // pixel tid + 256 k sits 3 rows and 55 columns (256 = 3 INW + 55) past pixel tid + 256 (k - 1)
+                static_assert(INW == 67 && INH * INW <= 5 * 256, "the walk below is written for the 19 x 67 tile");
+                int ly = tid / INW, lx = tid - ly * INW;
+                const bool inside = gx0 >= max(a.vx0, 0) && gx0 + INW <= min(a.vx1, net) && gy0 >= max(a.vy0, 0) && gy0 + INH <= min(a.vy1, net);
+                if (inside) {   // (three tiles in four) every pixel of the tile has both taps: nothing to test per pixel
+    #pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        if (k < 4 || tid < INH * INW - 4 * 256) s_in[ly * INP + lx] = blend(ly, lx, s_ty[ly]);
+                        lx += 256 - 3 * INW; ly += 3;
+                        if (lx >= INW) { lx -= INW; ly++; }
+                    }
+                } else {
+    #pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        if (k < 4 || tid < INH * INW - 4 * 256) {
+                            const int gx = gx0 + lx;
+                            half4 o = (half4){0, 0, 0, 0};
+                            if ((unsigned)(gy0 + ly) < (unsigned)net && (unsigned)gx < (unsigned)net) {
+                                const uint32_t ty = s_ty[ly];
+                                o = (ty == 0xffffffffu || gx < a.vx0 || gx >= a.vx1) ? (half4){padv, padv, padv, (half_t)0.0f} : blend(ly, lx, ty);
+                            }
+                            s_in[ly * INP + lx] = o;
+                        }
+                        lx += 256 - 3 * INW; ly += 3;
+                        if (lx >= INW) { lx -= INW; ly++; }
+                    }
                 }
             } else {
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    if (k < 4 || tid < INH * INW - 4 * 256) {
-                        const int gx = gx0 + lx;
-                        half4 o = (half4){0, 0, 0, 0};
-                        if ((unsigned)(gy0 + ly) < (unsigned)net && (unsigned)gx < (unsigned)net) {
-                            const uint32_t ty = s_ty[ly];
-                            o = (ty == 0xffffffffu || gx < a.vx0 || gx >= a.vx1) ? (half4){padv, padv, padv, (half_t)0.0f} : blend(ly, lx, ty);
+    #pragma unroll 5
+            for (int pp = tid; pp < INH * INW; pp += 256) {
+                const int ly = pp / INW, lx = pp - ly * INW;
+                const int p = ly * INP + lx;
+                half4 o = (half4){0, 0, 0, 0};
+                if ( (unsigned)(gy0 + ly) < (unsigned)net && (unsigned)(gx0 + lx) < (unsigned)net) {
+                    const uint32_t ty = s_ty[ly], tx = s_tx[lx];
+                    if (ty == 0xffffffffu || tx == 0xffffffffu) {
+                        o = (half4){padv, padv, padv, (half_t)0.0f};
+                    } else {
+                        const uint32_t *r0 = s_px + __umul24(ty & 1023u, pitch), *r1 = s_px + __umul24((ty >> 10) & 1023u, pitch);
+                        const uint32_t xa = tx & 1023u, xb = (tx >> 10) & 1023u;
+                        const uint32_t wx = tx >> 20, wy = ty >> 20;
+                        const uint32_t q00 = r0[xa], q01 = r0[xb], q10 = r1[xa], q11 = r1[xb];
+                        half_t v[3];
+    #pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const uint32_t p00 = (q00 >> (8 * c)) & 255u, p01 = (q01 >> (8 * c)) & 255u;
+                            const uint32_t p10 = (q10 >> (8 * c)) & 255u, p11 = (q11 >> (8 * c)) & 255u;
+                            // 24-bit multiplies (full rate): coefficients <= 2^11, pixels < 2^8, top / bot < 2^19
+                            const uint32_t top = __umul24(kCoefOne - wx, p00) + __umul24(wx, p01);
+                            const uint32_t bot = __umul24(kCoefOne - wx, p10) + __umul24(wx, p11);
+                            const uint32_t acc = __umul24(kCoefOne - wy, top) + __umul24(wy, bot);
+                            v[c] = (half_t)((float)((acc + (1u << (2 * kCoefBits - 1))) >> (2 * kCoefBits)) * inv255);
                         }
-                        s_in[ly * INP + lx] = o;
+                        if (a.swap_rb) { const half_t t = v[0]; v[0] = v[2]; v[2] = t; }
+                        o = (half4){v[0], v[1], v[2], (half_t)0.0f};
                     }
-                    lx += 256 - 3 * INW; ly += 3;
-                    if (lx >= INW) { lx -= INW; ly++; }
                 }
+                s_in[p] = o;
             }
-        } else {
-#pragma unroll 5
-        for (int pp = tid; pp < INH * INW; pp += 256) {
-            const int ly = pp / INW, lx = pp - ly * INW;
-            const int p = ly * INP + lx;
-            half4 o = (half4){0, 0, 0, 0};
-            if ( (unsigned)(gy0 + ly) < (unsigned)net && (unsigned)(gx0 + lx) < (unsigned)net) {
-                const uint32_t ty = s_ty[ly], tx = s_tx[lx];
-                if (ty == 0xffffffffu || tx == 0xffffffffu) {
-                    o = (half4){padv, padv, padv, (half_t)0.0f};
-                } else {
-                    const uint32_t *r0 = s_px + __umul24(ty & 1023u, pitch), *r1 = s_px + __umul24((ty >> 10) & 1023u, pitch);
-                    const uint32_t xa = tx & 1023u, xb = (tx >> 10) & 1023u;
-                    const uint32_t wx = tx >> 20, wy = ty >> 20;
-                    const uint32_t q00 = r0[xa], q01 = r0[xb], q10 = r1[xa], q11 = r1[xb];
-                    half_t v[3];
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const uint32_t p00 = (q00 >> (8 * c)) & 255u, p01 = (q01 >> (8 * c)) & 255u;
-                        const uint32_t p10 = (q10 >> (8 * c)) & 255u, p11 = (q11 >> (8 * c)) & 255u;
-                        // 24-bit multiplies (full rate): coefficients <= 2^11, pixels < 2^8, top / bot < 2^19
-                        const uint32_t top = __umul24(kCoefOne - wx, p00) + __umul24(wx, p01);
-                        const uint32_t bot = __umul24(kCoefOne - wx, p10) + __umul24(wx, p11);
-                        const uint32_t acc = __umul24(kCoefOne - wy, top) + __umul24(wy, bot);
-                        v[c] = (half_t)((float)((acc + (1u << (2 * kCoefBits - 1))) >> (2 * kCoefBits)) * inv255);
-                    }
-                    if (a.swap_rb) { const half_t t = v[0]; v[0] = v[2]; v[2] = t; }
-                    o = (half4){v[0], v[1], v[2], (half_t)0.0f};
-                }
             }
-            s_in[p] = o;
-        }
         }
     }
     FSTAMP(4);

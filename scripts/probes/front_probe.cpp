@@ -45,7 +45,7 @@ int main(int argc, char **argv)
     a.tx = to_dev(tx); a.ty = to_dev(ty);
     a.vx0 = 0; a.vx1 = net; a.vy0 = 0; a.vy1 = net;
     a.sw = sw; a.sh = sh; a.net = net; a.swap_rb = 1;
-    a.fastx = getenv("FASTX") ? atoi(getenv("FASTX")) : 1; a.fx_i0 = 0; a.fx_step = 2;
+    a.fastx = getenv("FASTX") ? atoi(getenv("FASTX")) : 3; a.fx_i0 = 0; a.fx_step = 2;
     std::vector<irmv::half_t> w0(2 * 64 * 8), w1(10 * 64 * 8);
     for (auto &v : w0) v = (irmv::half_t)(((int)(rnd() & 255) - 128) / 512.0f);
     for (auto &v : w1) v = (irmv::half_t)(((int)(rnd() & 255) - 128) / 1024.0f);
