@@ -510,7 +510,8 @@ def test_resident_weight_kernels_are_bitwise_the_chunked_ones(blob, monkeypatch,
 
 
 @pytest.mark.parametrize("switch", ["IRMV_INLINE_COPIES=1", "IRMV_ZERO_COPY_RESULTS=0", "IRMV_SPLIT_SCAN=0", "IRMV_EMIT_SCAN=0",
-                                    "IRMV_FUSED_HEAD=0", "IRMV_MERGE_HEAD0=0", "IRMV_GROUP_HEAD=0", "IRMV_NO_PF2=1", "IRMV_NO_DEEP=1"])
+                                    "IRMV_FUSED_HEAD=0", "IRMV_MERGE_HEAD0=0", "IRMV_GROUP_HEAD=0", "IRMV_NO_PF2=1", "IRMV_NO_DEEP=1",
+                                    "IRMV_FRONT_FASTX=0", "IRMV_FRONT_DIRECT=0"])
 def test_every_remaining_switch_is_bitwise_the_default(blob, monkeypatch, switch):
     """The environment switches that select between implementations of the same arithmetic (where the copies ride, where the
     results land, where candidates are found, which launches are merged): heads and detections of a batched step, of
@@ -758,6 +759,8 @@ def test_pipelined_slots_overlap_and_match_detect(blob):
     ((644, 480), 640, 0, False, False, True),      # up-scale in x: a tile's source region is narrower than the tile
     ((1280, 720), 640, 1, False, True, True),      # letterbox bands above and below
     ((800, 600), 416, 1, True, False, True),
+    ((1276, 1280), 640, 1, True, False, True),     # 2 : 1 columns behind ONE pad column: the direct tiles' column pairs start inside the tile (step -2)
+    ((1276, 1280), 640, 1, False, True, True),     # ... and step +2
     ((641, 479), 640, 0, True, False, False),      # width not a multiple of 4: falls back to the three kernels
     ((4096, 3000), 640, 0, True, False, False),    # tile's source region larger than the LDS stage: falls back
 ])
