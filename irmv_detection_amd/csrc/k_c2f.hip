@@ -347,18 +347,29 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) B[ks] = as_h8(keep_if(inside, Bn[ks]));   // the select waits for the load: here, not at issue
             if (t + 4 < R1N / 16) load_tile(t + 4, Bn);
+            // y0 (output tiles 0, 1) is needed on the 8 x 16 tile only: a run of 16 region pixels that lies entirely in the halo
+            // rows (the region's first and last two: MFMA tiles 0, 1, 13, 14 of 15) computes y1 alone -- half the MFMAs and
+            // half the SiLUs of those tiles (the wave-uniform branch costs nothing; nothing of y0 was stored for them anyway)
+            const bool want_y0 = t * 16 + 15 >= 2 * R1W && t * 16 < (R1H - 2) * R1W;
             f32x4 acc[4];
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (want_y0) {
 #pragma unroll
-            for (int ks = 0; ks < KS1; ks++)
+                for (int ks = 0; ks < KS1; ks++)
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[nt][ks], B[ks], acc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[nt][ks], B[ks], acc[nt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS1; ks++)
+#pragma unroll
+                    for (int nt = 2; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[nt][ks], B[ks], acc[nt], 0, 0, 0);
+            }
             half8 o[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 o[u] = zero8;   // outside the image y1 is the bottleneck's zero padding
-                if (inside) {
+                if (inside && (u == 1 || want_y0)) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         o[u][i] = (IRMV_ABL & 8) ? (half_t)(acc[2 * u][i] + bias[u * 8 + i]) : (half_t)silu(acc[2 * u][i] + bias[u * 8 + i]);
