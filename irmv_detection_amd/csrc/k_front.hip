@@ -21,6 +21,8 @@
 // (tests/test_gpu_engine.py::test_fused_kernels_are_bitwise_identical).
 #include "irmv_common.hpp"
 
+#include <type_traits>
+
 namespace irmv {
 
 namespace {
@@ -79,81 +81,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
     const half8 *wp0 = reinterpret_cast<const half8 *>(a.w0) + lane;
     const half8 A00 = wp0[0], A01 = wp0[64];
 
-    // ---- direct tiles (round 3): columns at exactly 2 : 1 and no padding pixel anywhere in the tile.  Every source pixel
-    // of such a tile feeds exactly one net-input pixel of it in x, so staging the region in LDS first (A1: 12-byte groups
-    // -> 4-byte pixels, a barrier, then A2's reads) is pure overhead: a thread loads the 12 bytes = two aligned source
-    // pairs of TWO tap rows straight into registers and blends two adjacent net-input pixels from them.  Same integers as
-    // A2's 2 : 1 path (sum of the pair, vertical blend, one rounding shift), so the same bits.
+    // ---- direct tiles (round 3): columns at exactly 2 : 1.  Every source pixel of a tile then feeds exactly one of its
+    // net-input pixels in x, so staging the region in LDS first (A1: 12-byte groups -> 4-byte pixels, a barrier, then A2's
+    // reads) is pure overhead: a thread loads the 12 bytes = two aligned source pairs of TWO tap rows straight into
+    // registers and blends two adjacent net-input pixels from them.  Same integers as A2's 2 : 1 path (sum of the pair,
+    // vertical blend, one rounding shift), so the same bits.  Tiles that contain padding or out-of-image pixels (EDGE) load
+    // from clamped addresses and select the constant afterwards.
     const bool tile_inside = gx0 >= max(a.vx0, 0) && gx0 + INW <= min(a.vx1, net) && gy0 >= max(a.vy0, 0) && gy0 + INH <= min(a.vy1, net);
-    bool direct = false;
-    int dg0 = 0, de = 0;
-    if ((a.fastx & 2) && tile_inside) {
-        const int mq = a.fx_i0 + a.fx_step * (gx0 - a.vx0);                       // source pair of the tile's first column
-        // a 12-byte group = source pixels g .. g + 3 (g a multiple of 4) = the pairs of two adjacent columns; the tile's
-        // columns are paired from column -de on so that every pair of columns is one such group
-        de = a.fx_step > 0 ? ((mq & 3) == 0 ? 0 : 1) : ((mq & 3) == 2 ? 0 : 1);
-        direct = de ? (gx0 - 1 >= a.vx0) : (gx0 + INW < a.vx1);                   // the one column outside the tile must have a source too
-        dg0 = a.fx_step > 0 ? mq - 2 * de : mq + 2 * de - 2;                        // group of the first pair of columns
-    }
+    const bool direct = (a.fastx & 2) != 0;
     if (direct) {
         constexpr int NPAIR = (INW + 1) / 2, NIT = INH * NPAIR;                    // 34 pairs x 19 rows = 646 items: three trips
         static_assert(NPAIR == 34 && NIT > 512 && NIT <= 768, "the walk below is written for the 19 x 67 tile");
+        // a 12-byte group = source pixels g .. g + 3 (g a multiple of 4) = the pairs of two adjacent columns; the tile's
+        // columns are paired from column -de on so that every pair of columns is one such group.  The group of a column
+        // that has a source lies inside the source row (pairs are even, sw is a multiple of 4), whatever its neighbour is.
+        const int mq = a.fx_i0 + a.fx_step * (gx0 - a.vx0);                       // source pair of the tile's first column
+        const int de = a.fx_step > 0 ? ((mq & 3) == 0 ? 0 : 1) : ((mq & 3) == 2 ? 0 : 1);
+        const int dg0 = a.fx_step > 0 ? mq - 2 * de : mq + 2 * de - 2;            // group of the first pair of columns
         const uint8_t *srcb = a.src + (size_t)b * a.src_slot_bytes;
         const uint32_t row_bytes = (uint32_t)a.sw * 3u;
-        const int sgn12 = a.fx_step > 0 ? 12 : -12;
-        int row = tid / NPAIR, p = tid - row * NPAIR;
-        int rowv[3], pv[3];
-        AxisTap tp[3];
+        const int sgn4 = a.fx_step > 0 ? 4 : -4;
+        auto run_direct = [&](auto edge_c) {
+            constexpr bool EDGE = decltype(edge_c)::value;
+            int row = tid / NPAIR, p = tid - row * NPAIR;
+            int rowv[3], pv[3];
+            AxisTap tp[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            rowv[k] = row; pv[k] = p;
-            tp[k] = a.ty[gy0 + min(row, INH - 1)];                                  // (the third trip's idle lanes: the last row again)
-            p += 256 - 7 * NPAIR; row += 7;
-            if (p >= NPAIR) { p -= NPAIR; row++; }
-        }
-        uint32_t dd[3][6];
+            for (int k = 0; k < 3; k++) {
+                rowv[k] = row; pv[k] = p;
+                int gy = gy0 + min(row, INH - 1);                                   // (the third trip's idle lanes: the last row again)
+                if (EDGE) gy = min(max(gy, a.vy0), a.vy1 - 1);                      // a row without a source: any row's tap, the result is replaced
+                tp[k] = a.ty[gy];
+                p += 256 - 7 * NPAIR; row += 7;
+                if (p >= NPAIR) { p -= NPAIR; row++; }
+            }
+            uint32_t dd[3][6];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t xo = (uint32_t)(3 * dg0 + sgn12 * pv[k]);
-            const uint32_t *q0 = reinterpret_cast<const uint32_t *>(srcb + (uint32_t)tp[k].i0 * row_bytes + xo);
-            const uint32_t *q1 = reinterpret_cast<const uint32_t *>(srcb + (uint32_t)tp[k].i1 * row_bytes + xo);
-            dd[k][0] = q0[0]; dd[k][1] = q0[1]; dd[k][2] = q0[2];
-            dd[k][3] = q1[0]; dd[k][4] = q1[1]; dd[k][5] = q1[2];
-        }
-        if (tid < 48) s_bias[tid] = bias_v;
-        if (tid < INH) s_in[tid * INP + INW] = (half4){0, 0, 0, 0};               // the extra column of every row stays zero
+            for (int k = 0; k < 3; k++) {
+                int gi = dg0 + sgn4 * pv[k];
+                if (EDGE) gi = min(max(gi, 0), a.sw - 4);                           // both columns without a source
+                const uint32_t xo = (uint32_t)(3 * gi);
+                const uint32_t *q0 = reinterpret_cast<const uint32_t *>(srcb + (uint32_t)tp[k].i0 * row_bytes + xo);
+                const uint32_t *q1 = reinterpret_cast<const uint32_t *>(srcb + (uint32_t)tp[k].i1 * row_bytes + xo);
+                dd[k][0] = q0[0]; dd[k][1] = q0[1]; dd[k][2] = q0[2];
+                dd[k][3] = q1[0]; dd[k][4] = q1[1]; dd[k][5] = q1[2];
+            }
+            if (tid < 48) s_bias[tid] = bias_v;
+            if (tid < INH) s_in[tid * INP + INW] = (half4){0, 0, 0, 0};           // the extra column of every row stays zero
+            const float inv255 = 1.0f / 255.0f;
+            const uint32_t rnd = 1u << kCoefBits;
+            const half_t padv = (half_t)(114.0f / 255.0f);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (k == 2 && tid >= NIT - 512) break;
+                const uint32_t wy = (uint32_t)tp[k].w1, wy0 = kCoefOne - wy;
+                // bytes of a row's group: pixel 0 = b0 b1 b2, 1 = b3 b4 b5, 2 = b6 b7 b8, 3 = b9 b10 b11; first half = pixels 0 + 1
+                uint32_t rb[2][2], gg[2][2];   // [tap row][half]: channel 0 and 2 sums side by side, channel 1 sum
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const uint32_t d0 = dd[k][3 * t], d1 = dd[k][3 * t + 1], d2 = dd[k][3 * t + 2];
+                    rb[t][0] = (d0 & 0x00ff00ffu) + __builtin_amdgcn_perm(d1, d0, 0x0c050c03u);            // (b0, b2) + (b3, b5)
+                    gg[t][0] = ((d0 >> 8) & 255u) + (d1 & 255u);                                             // b1 + b4
+                    rb[t][1] = __builtin_amdgcn_perm(d2, d1, 0x0c040c02u) + ((d2 >> 8) & 0x00ff00ffu);      // (b6, b8) + (b9, b11)
+                    gg[t][1] = (d1 >> 24) + ((d2 >> 16) & 255u);                                             // b7 + b10
+                }
+                const int lxa = 2 * pv[k] - de;
+                const int gy = gy0 + rowv[k];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {   // column lxa + h: the first half of the group under step +2, the second under -2
+                    const int hs = a.fx_step > 0 ? h : 1 - h;
+                    const uint32_t rb0 = hs ? rb[0][1] : rb[0][0], rb1 = hs ? rb[1][1] : rb[1][0];
+                    const uint32_t g0v = hs ? gg[0][1] : gg[0][0], g1v = hs ? gg[1][1] : gg[1][0];
+                    const uint32_t c0 = (__umul24(wy0, rb0 & 0xffffu) + __umul24(wy, rb1 & 0xffffu) + rnd) >> (kCoefBits + 1);
+                    const uint32_t c1 = (__umul24(wy0, g0v) + __umul24(wy, g1v) + rnd) >> (kCoefBits + 1);
+                    const uint32_t c2 = (__umul24(wy0, rb0 >> 16) + __umul24(wy, rb1 >> 16) + rnd) >> (kCoefBits + 1);
+                    half_t v0 = (half_t)((float)c0 * inv255), v1 = (half_t)((float)c1 * inv255), v2 = (half_t)((float)c2 * inv255);
+                    if (a.swap_rb) { const half_t t = v0; v0 = v2; v2 = t; }
+                    const int lx = lxa + h;
+                    half4 o = (half4){v0, v1, v2, (half_t)0.0f};
+                    if (EDGE) {   // outside the net input: the convolution's zero padding; inside without a source: the letterbox grey
+                        const int gx = gx0 + lx;
+                        const bool in_net = (unsigned)gy < (unsigned)net && (unsigned)gx < (unsigned)net;
+                        const bool has_src = gy >= a.vy0 && gy < a.vy1 && gx >= a.vx0 && gx < a.vx1;
+                        o = !in_net ? (half4){0, 0, 0, 0} : (has_src ? o : (half4){padv, padv, padv, (half_t)0.0f});
+                    }
+                    if ((unsigned)lx < (unsigned)INW) s_in[rowv[k] * INP + lx] = o;
+                }
+            }
+        };
+        if (tile_inside) run_direct(std::false_type{}); else run_direct(std::true_type{});
         FSTAMP(1); FSTAMP(2); FSTAMP(3);
-        const float inv255 = 1.0f / 255.0f;
-        const uint32_t rnd = 1u << kCoefBits;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            if (k == 2 && tid >= NIT - 512) break;
-            const uint32_t wy = (uint32_t)tp[k].w1, wy0 = kCoefOne - wy;
-            // bytes of a row's group: pixel 0 = b0 b1 b2, 1 = b3 b4 b5, 2 = b6 b7 b8, 3 = b9 b10 b11; first half = pixels 0 + 1
-            uint32_t rb[2][2], gg[2][2];   // [tap row][half]: channel 0 and 2 sums side by side, channel 1 sum
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const uint32_t d0 = dd[k][3 * t], d1 = dd[k][3 * t + 1], d2 = dd[k][3 * t + 2];
-                rb[t][0] = (d0 & 0x00ff00ffu) + __builtin_amdgcn_perm(d1, d0, 0x0c050c03u);            // (b0, b2) + (b3, b5)
-                gg[t][0] = ((d0 >> 8) & 255u) + (d1 & 255u);                                             // b1 + b4
-                rb[t][1] = __builtin_amdgcn_perm(d2, d1, 0x0c040c02u) + ((d2 >> 8) & 0x00ff00ffu);      // (b6, b8) + (b9, b11)
-                gg[t][1] = (d1 >> 24) + ((d2 >> 16) & 255u);                                             // b7 + b10
-            }
-            const int lxa = 2 * pv[k] - de;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {   // column lxa + h: the first half of the group under step +2, the second under -2
-                const int hs = a.fx_step > 0 ? h : 1 - h;
-                const uint32_t rb0 = hs ? rb[0][1] : rb[0][0], rb1 = hs ? rb[1][1] : rb[1][0];
-                const uint32_t g0v = hs ? gg[0][1] : gg[0][0], g1v = hs ? gg[1][1] : gg[1][0];
-                const uint32_t c0 = (__umul24(wy0, rb0 & 0xffffu) + __umul24(wy, rb1 & 0xffffu) + rnd) >> (kCoefBits + 1);
-                const uint32_t c1 = (__umul24(wy0, g0v) + __umul24(wy, g1v) + rnd) >> (kCoefBits + 1);
-                const uint32_t c2 = (__umul24(wy0, rb0 >> 16) + __umul24(wy, rb1 >> 16) + rnd) >> (kCoefBits + 1);
-                half_t v0 = (half_t)((float)c0 * inv255), v1 = (half_t)((float)c1 * inv255), v2 = (half_t)((float)c2 * inv255);
-                if (a.swap_rb) { const half_t t = v0; v0 = v2; v2 = t; }
-                const int lx = lxa + h;
-                if ((unsigned)lx < (unsigned)INW) s_in[rowv[k] * INP + lx] = (half4){v0, v1, v2, (half_t)0.0f};
-            }
-        }
     } else {
     // ---- 0: bounding box of the source pixels the tile touches.  The tap tables are monotonic, so the box follows
         // from the taps of the first and last in-image row / column of the tile (uniform addresses: scalar loads), and the
