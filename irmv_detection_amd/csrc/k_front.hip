@@ -131,33 +131,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
             const float inv255 = 1.0f / 255.0f;
             const uint32_t rnd = 1u << kCoefBits;
             const half_t padv = (half_t)(114.0f / 255.0f);
+            // v_perm_b32 selectors (byte i of the result: 0..3 = bytes of the second operand, 4..7 = of the first, 0x0c = zero)
+            const uint32_t sel00 = a.swap_rb ? 0x0c000c02u : 0x0c020c00u, sel01 = a.swap_rb ? 0x0c030c05u : 0x0c050c03u;
+            const uint32_t sel10 = a.swap_rb ? 0x0c020c04u : 0x0c040c02u, sel11 = a.swap_rb ? 0x0c010c03u : 0x0c030c01u;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 if (k == 2 && tid >= NIT - 512) break;
                 const uint32_t wy = (uint32_t)tp[k].w1, wy0 = kCoefOne - wy;
-                // bytes of a row's group: pixel 0 = b0 b1 b2, 1 = b3 b4 b5, 2 = b6 b7 b8, 3 = b9 b10 b11; first half = pixels 0 + 1
-                uint32_t rb[2][2], gg[2][2];   // [tap row][half]: channel 0 and 2 sums side by side, channel 1 sum
+                // bytes of a row's group: pixel 0 = b0 b1 b2, 1 = b3 b4 b5, 2 = b6 b7 b8, 3 = b9 b10 b11; first half = pixels 0 + 1.
+                // The byte selectors put the channel that becomes output channel 0 in the low half (swap_rb: uniform, scalar)
+                uint32_t rb[2][2], gg[2][2];   // [tap row][half]: first and third output channel's sums side by side, channel 1 sum
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const uint32_t d0 = dd[k][3 * t], d1 = dd[k][3 * t + 1], d2 = dd[k][3 * t + 2];
-                    rb[t][0] = (d0 & 0x00ff00ffu) + __builtin_amdgcn_perm(d1, d0, 0x0c050c03u);            // (b0, b2) + (b3, b5)
+                    rb[t][0] = __builtin_amdgcn_perm(d0, d0, sel00) + __builtin_amdgcn_perm(d1, d0, sel01);   // (b0, b2) + (b3, b5)
                     gg[t][0] = ((d0 >> 8) & 255u) + (d1 & 255u);                                             // b1 + b4
-                    rb[t][1] = __builtin_amdgcn_perm(d2, d1, 0x0c040c02u) + ((d2 >> 8) & 0x00ff00ffu);      // (b6, b8) + (b9, b11)
+                    rb[t][1] = __builtin_amdgcn_perm(d2, d1, sel10) + __builtin_amdgcn_perm(d2, d2, sel11);   // (b6, b8) + (b9, b11)
                     gg[t][1] = (d1 >> 24) + ((d2 >> 16) & 255u);                                             // b7 + b10
                 }
                 const int lxa = 2 * pv[k] - de;
                 const int gy = gy0 + rowv[k];
 #pragma unroll
-                for (int h = 0; h < 2; h++) {   // column lxa + h: the first half of the group under step +2, the second under -2
-                    const int hs = a.fx_step > 0 ? h : 1 - h;
-                    const uint32_t rb0 = hs ? rb[0][1] : rb[0][0], rb1 = hs ? rb[1][1] : rb[1][0];
-                    const uint32_t g0v = hs ? gg[0][1] : gg[0][0], g1v = hs ? gg[1][1] : gg[1][0];
+                for (int h = 0; h < 2; h++) {   // half h of the group: column lxa + h under step +2, lxa + 1 - h under -2
+                    const uint32_t rb0 = rb[0][h], rb1 = rb[1][h], g0v = gg[0][h], g1v = gg[1][h];
                     const uint32_t c0 = (__umul24(wy0, rb0 & 0xffffu) + __umul24(wy, rb1 & 0xffffu) + rnd) >> (kCoefBits + 1);
                     const uint32_t c1 = (__umul24(wy0, g0v) + __umul24(wy, g1v) + rnd) >> (kCoefBits + 1);
                     const uint32_t c2 = (__umul24(wy0, rb0 >> 16) + __umul24(wy, rb1 >> 16) + rnd) >> (kCoefBits + 1);
-                    half_t v0 = (half_t)((float)c0 * inv255), v1 = (half_t)((float)c1 * inv255), v2 = (half_t)((float)c2 * inv255);
-                    if (a.swap_rb) { const half_t t = v0; v0 = v2; v2 = t; }
-                    const int lx = lxa + h;
+                    const half_t v0 = (half_t)((float)c0 * inv255), v1 = (half_t)((float)c1 * inv255), v2 = (half_t)((float)c2 * inv255);
+                    const int lx = lxa + (a.fx_step > 0 ? h : 1 - h);
                     half4 o = (half4){v0, v1, v2, (half_t)0.0f};
                     if (EDGE) {   // outside the net input: the convolution's zero padding; inside without a source: the letterbox grey
                         const int gx = gx0 + lx;
