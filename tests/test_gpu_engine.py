@@ -68,6 +68,8 @@ def _raw_tuple(r):
     ((640, 640), 0, True, False),        # BASELINE configs[1]: identity scale
     ((641, 479), 0, True, False),        # rows not 16-byte aligned -> scalar staging path
     ((333, 1000), 1, False, False),
+    ((1276, 1280), 1, True, False),      # 2 : 1 behind one pad column (the fused front's direct tiles with de = 0: test_fused_kernels_are_bitwise_identical)
+    ((1276, 1280), 1, False, True),
 ])
 def test_preprocess_bit_exact(blob, size, mode, rot, swap):
     rng = np.random.default_rng(7)
