@@ -235,7 +235,7 @@ struct irmv_engine {
     long long *dbg_dev = nullptr;
     std::set<std::string> lazy_tensors;   // tensors a step does not write because a fused kernel keeps them on chip
     bool fused_front = false;          // OP_FRONT replaces preprocess + model.0.conv + model.1.conv in a step
-    int front_tiles_x = 0, front_tiles_y = 0, front_stage_bytes = 0;
+    int front_tiles_x = 0, front_tiles_y = 0, front_stage_bytes = 0, front_tile_y = kFrontTileY;
     int front_v[4] = {0, 0, 0, 0};     // valid (non-padding) net-input column / row ranges
     int front_fastx = 0, front_fx_i0 = 0, front_fx_step = 2;   // every x tap is (i0 + 2 k, i0 + 2 k + 1; 1/2): the front kernel's 2 : 1 column path
     bool classical = false;            // four points from the classical light extraction instead of a keypoint head
@@ -722,6 +722,14 @@ static int build_engine(irmv_engine *e)
         bool direct = fx;   // tiles without a padding pixel skip the LDS staging of the source (k_front.hip); bit 1 of FrontArgs::fastx
         if (const char *f = getenv("IRMV_FRONT_DIRECT")) if (f[0] == '0') direct = false;
         e->front_fastx = fx ? (direct ? 3 : 1) : 0;
+        // all tiles direct: nothing is staged, and the tile can be twice as tall (k_front.hip); IRMV_FRONT_TILE8=0 keeps the 4-row tile
+        bool tall = fx && direct && e->fused_front;
+        if (const char *f = getenv("IRMV_FRONT_TILE8")) if (f[0] == '0') tall = false;
+        if (tall) {
+            e->front_tile_y = kFrontTileYDirect;
+            e->front_tiles_y = (net / 4 + kFrontTileYDirect - 1) / kFrontTileYDirect;
+            e->front_stage_bytes = front_min_stage_bytes(kFrontTileYDirect);
+        }
         e->front_fx_i0 = fx ? m0 : 0;
         e->front_fx_step = step;
     }
@@ -1818,7 +1826,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
             const Tensor &ot = e->tensors[op.out_t];
             a.out = static_cast<half_t *>(ot.slot(first));
             a.out_ld = ot.C;
-            a.tiles_x = e->front_tiles_x; a.tiles_y = e->front_tiles_y;
+            a.tiles_x = e->front_tiles_x; a.tiles_y = e->front_tiles_y; a.tile_y = e->front_tile_y;
             a.stage_bytes = e->front_stage_bytes;
             if (!launch_front(a, count, s)) return fail(IRMV_ERR_HIP, "fused front kernel: LDS request refused");
             break;

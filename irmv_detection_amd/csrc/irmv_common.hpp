@@ -46,6 +46,7 @@ void launch_conv0(const Conv0Args &a, hipStream_t s);
 
 // fused front: preprocess + model.0.conv + model.1.conv (k_front.hip)
 constexpr int kFrontTileY = 4, kFrontTileX = 16;   // model.1 output tile of one workgroup
+constexpr int kFrontTileYDirect = 8;               // ... of engines whose tiles all read their source directly (columns at exactly 2 : 1)
 constexpr int kFrontStageMax = 128 * 1024;         // most LDS the tile's source region may take (else: the three kernels)
 struct FrontArgs {
     const uint8_t *src;   // [B][sh][sw][3]
@@ -61,9 +62,10 @@ struct FrontArgs {
     half_t *out;          // [B][net/4][net/4][out_ld]
     int out_ld;
     int tiles_x, tiles_y;
-    int stage_bytes;      // dynamic LDS: >= the largest tile's source region and >= front_min_stage_bytes()
+    int tile_y;           // kFrontTileY, or kFrontTileYDirect (needs fastx bit 1)
+    int stage_bytes;      // dynamic LDS: >= the largest tile's source region (staged path) and >= front_min_stage_bytes(tile_y)
 };
-int front_min_stage_bytes();
+int front_min_stage_bytes(int tile_y = kFrontTileY);
 bool front_prepare();
 bool launch_front(const FrontArgs &a, int batch, hipStream_t s);
 

@@ -28,11 +28,10 @@ namespace irmv {
 namespace {
 constexpr int kCoefBits = 11;
 constexpr int kCoefOne = 1 << kCoefBits;
-constexpr int TY = kFrontTileY, TX = kFrontTileX;   // model.1 output tile
-constexpr int C0H = 2 * TY + 1, C0W = 2 * TX + 1;    // model.0 outputs it needs
+constexpr int TX = kFrontTileX;                      // model.1 output tile: TY x TX, TY = 4 (staged source) or 8 (direct tiles)
+constexpr int C0W = 2 * TX + 1;                      // model.0 output columns it needs
 constexpr int C0HALF = (C0W + 1) / 2;                // columns per parity plane
-constexpr int INH = 4 * TY + 3, INW = 4 * TX + 3;    // net-input pixels those need
-constexpr int MTC = TY / 4;                          // model.1 output rows per wave
+constexpr int INW = 4 * TX + 3;                      // net-input columns those need
 constexpr int INP = INW + 1;                         // row pitch (pixels); the extra column stays zero
 }  // namespace
 
@@ -43,8 +42,16 @@ __device__ unsigned long long g_front_stamps[65536 * 9];   // probe builds: shad
 #define FSTAMP(k)
 #endif
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void front_kernel(FrontArgs a)   // 5 waves per SIMD = 96 VGPRs: the occupancy step the kernel sat on before its biases moved to LDS
+// TY = 4: 5 waves per SIMD = 96 VGPRs (the occupancy step the kernel sat on before its biases moved to LDS).  TY = 8 (round 3,
+// engines whose tiles are all direct): twice the tile on the same four waves -- the halo of the two stride-2 convs costs
+// 1.15 x / 1.10 x instead of 1.24 x / 1.16 x the pixels, the per-workgroup prologue is paid half as often, and the direct
+// walk fills 93 % of its lane slots instead of 84 %; 38 KB of LDS -> 4 workgroups per CU.
+template <int TY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5 : 4))) void front_kernel(FrontArgs a)
 {
+    constexpr int C0H = 2 * TY + 1;                      // model.0 output rows the tile needs
+    constexpr int INH = 4 * TY + 3;                      // net-input rows those need
+    constexpr int MTC = TY / 4;                          // model.1 output rows per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // a.stage_bytes: source region, later model.0's tile
     __shared__ __attribute__((aligned(16))) half4 s_in[INH * INP];
     __shared__ uint32_t s_tx[INW], s_ty[INH];   // packed region-relative taps
@@ -90,8 +97,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
     const bool tile_inside = gx0 >= max(a.vx0, 0) && gx0 + INW <= min(a.vx1, net) && gy0 >= max(a.vy0, 0) && gy0 + INH <= min(a.vy1, net);
     const bool direct = (a.fastx & 2) != 0;
     if (direct) {
-        constexpr int NPAIR = (INW + 1) / 2, NIT = INH * NPAIR;                    // 34 pairs x 19 rows = 646 items: three trips
-        static_assert(NPAIR == 34 && NIT > 512 && NIT <= 768, "the walk below is written for the 19 x 67 tile");
+        constexpr int NPAIR = (INW + 1) / 2, NIT = INH * NPAIR;                    // 34 pairs x 19 (35) rows = 646 (1190) items
+        constexpr int NTRIP = (NIT + 255) / 256;                                   // three (five) trips
+        static_assert(NPAIR == 34, "the walk below steps 256 = 7 rows + 18 pairs");
         // a 12-byte group = source pixels g .. g + 3 (g a multiple of 4) = the pairs of two adjacent columns; the tile's
         // columns are paired from column -de on so that every pair of columns is one such group.  The group of a column
         // that has a source lies inside the source row (pairs are even, sw is a multiple of 4), whatever its neighbour is.
@@ -104,20 +112,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         auto run_direct = [&](auto edge_c) {
             constexpr bool EDGE = decltype(edge_c)::value;
             int row = tid / NPAIR, p = tid - row * NPAIR;
-            int rowv[3], pv[3];
-            AxisTap tp[3];
+            int rowv[NTRIP], pv[NTRIP];
+            AxisTap tp[NTRIP];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < NTRIP; k++) {
                 rowv[k] = row; pv[k] = p;
-                int gy = gy0 + min(row, INH - 1);                                   // (the third trip's idle lanes: the last row again)
+                int gy = gy0 + min(row, INH - 1);                                   // (the last trip's idle lanes: the last row again)
                 if (EDGE) gy = min(max(gy, a.vy0), a.vy1 - 1);                      // a row without a source: any row's tap, the result is replaced
                 tp[k] = a.ty[gy];
                 p += 256 - 7 * NPAIR; row += 7;
                 if (p >= NPAIR) { p -= NPAIR; row++; }
             }
-            uint32_t dd[3][6];
+            uint32_t dd[NTRIP][6];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < NTRIP; k++) {
                 int gi = dg0 + sgn4 * pv[k];
                 if (EDGE) gi = min(max(gi, 0), a.sw - 4);                           // both columns without a source
                 const uint32_t xo = (uint32_t)(3 * gi);
@@ -135,8 +143,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
             const uint32_t sel00 = a.swap_rb ? 0x0c000c02u : 0x0c020c00u, sel01 = a.swap_rb ? 0x0c030c05u : 0x0c050c03u;
             const uint32_t sel10 = a.swap_rb ? 0x0c020c04u : 0x0c040c02u, sel11 = a.swap_rb ? 0x0c010c03u : 0x0c030c01u;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (k == 2 && tid >= NIT - 512) break;
+            for (int k = 0; k < NTRIP; k++) {
+                if (k == NTRIP - 1 && tid >= NIT - 256 * (NTRIP - 1)) break;
                 const uint32_t wy = (uint32_t)tp[k].w1, wy0 = kCoefOne - wy;
                 // bytes of a row's group: pixel 0 = b0 b1 b2, 1 = b3 b4 b5, 2 = b6 b7 b8, 3 = b9 b10 b11; first half = pixels 0 + 1.
                 // The byte selectors put the channel that becomes output channel 0 in the low half (swap_rb: uniform, scalar)
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
         };
         if (tile_inside) run_direct(std::false_type{}); else run_direct(std::true_type{});
         FSTAMP(1); FSTAMP(2); FSTAMP(3);
-    } else {
+    } else if constexpr (TY == 4) {
     // ---- 0: bounding box of the source pixels the tile touches.  The tap tables are monotonic, so the box follows
         // from the taps of the first and last in-image row / column of the tile (uniform addresses: scalar loads), and the
         // source loads of A1 can be issued at once instead of behind a table read and a reduction.
@@ -502,19 +510,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
 #endif
 }
 
-int front_min_stage_bytes() { return C0H * 2 * C0HALF * 32; }
+int front_min_stage_bytes(int tile_y) { return (2 * tile_y + 1) * 2 * C0HALF * 32; }
 
-// Raises the kernel's dynamic-LDS limit (default 64 KiB); call once per process before the first launch / capture.
+// Raises the kernels' dynamic-LDS limit (default 64 KiB); call once per process before the first launch / capture.
 bool front_prepare()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kFrontStageMax) == hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(front_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kFrontStageMax) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void *>(front_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kFrontStageMax) == hipSuccess;
 }
 
 bool launch_front(const FrontArgs &a, int batch, hipStream_t s)
 {
-    if (a.stage_bytes < front_min_stage_bytes() || a.stage_bytes > kFrontStageMax) return false;
-    hipLaunchKernelGGL(front_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(256), (size_t)a.stage_bytes, s, a);
+    if (a.stage_bytes < front_min_stage_bytes(a.tile_y) || a.stage_bytes > kFrontStageMax) return false;
+    const dim3 grid(a.tiles_x * a.tiles_y, batch);
+    if (a.tile_y == kFrontTileY) hipLaunchKernelGGL(front_kernel<kFrontTileY>, grid, dim3(256), (size_t)a.stage_bytes, s, a);
+    else if (a.tile_y == kFrontTileYDirect && (a.fastx & 2)) hipLaunchKernelGGL(front_kernel<kFrontTileYDirect>, grid, dim3(256), (size_t)a.stage_bytes, s, a);   // the tall tile has no staged path
+    else return false;
     return true;
 }
 

@@ -54,7 +54,8 @@ int main(int argc, char **argv)
     irmv::half_t *out = nullptr;
     CK(hipMalloc(&out, (size_t)B * W1 * W1 * 32 * 2));
     a.out = out; a.out_ld = 32;
-    a.tiles_x = (W1 + irmv::kFrontTileX - 1) / irmv::kFrontTileX; a.tiles_y = (W1 + irmv::kFrontTileY - 1) / irmv::kFrontTileY;
+    a.tile_y = (getenv("TILE8") ? atoi(getenv("TILE8")) : 1) && (a.fastx & 2) ? irmv::kFrontTileYDirect : irmv::kFrontTileY;
+    a.tiles_x = (W1 + irmv::kFrontTileX - 1) / irmv::kFrontTileX; a.tiles_y = (W1 + a.tile_y - 1) / a.tile_y;
     {   // largest source region of a tile (engine.cpp front_fits)
         auto span = [&](const std::vector<AxisTap> &t, int g0, int n, int *lo, int *hi) {
             *lo = 0x7fffffff; *hi = -1;
@@ -63,7 +64,7 @@ int main(int argc, char **argv)
         int mp = 0, mr = 0, lo, hi;
         for (int i = 0; i < a.tiles_x; i++) { span(tx, 4 * i * irmv::kFrontTileX - 3, 4 * irmv::kFrontTileX + 3, &lo, &hi); mp = std::max(mp, std::min((hi + 4) & ~3, sw) - (lo & ~3)); }
         for (int i = 0; i < a.tiles_y; i++) { span(ty, 4 * i * irmv::kFrontTileY - 3, 4 * irmv::kFrontTileY + 3, &lo, &hi); mr = std::max(mr, hi - lo + 1); }
-        a.stage_bytes = std::max((mp * mr * 4 + 255) & ~255, irmv::front_min_stage_bytes());
+        a.stage_bytes = a.tile_y == irmv::kFrontTileY ? std::max((mp * mr * 4 + 255) & ~255, irmv::front_min_stage_bytes()) : irmv::front_min_stage_bytes(a.tile_y);
         printf("tiles %d x %d, region <= %d px x %d rows, stage %d B\n", a.tiles_x, a.tiles_y, mp, mr, a.stage_bytes);
     }
     if (!irmv::front_prepare()) { fprintf(stderr, "front_prepare failed\n"); return 2; }
