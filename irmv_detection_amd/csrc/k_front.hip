@@ -376,45 +376,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5
     __syncthreads();
     FSTAMP(5);
 
-    // ---- B: model.0.conv on the tile: 17 x 33 output pixels, 16 channels, K = [kh][4 tap slots][4 ch] ----
+    // ---- B: model.0.conv on the tile: C0H x 33 output pixels, 16 channels, K = [kh][4 tap slots][4 ch] ----
     // s_c0: parity-split columns ([row][column parity][column / 2][16 ch], 32 B per pixel): the stride-2
     // fragment reads of stage C then walk consecutive 32-byte slots (conflict-free ds_read_b128).
     half_t *s_c0 = reinterpret_cast<half_t *>(s_stage);
     {
-        constexpr int NPX = C0H * C0W, NTILES = (NPX + 15) / 16;
         const half4 z4 = (half4){0, 0, 0, 0};
         float bias0[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) bias0[i] = s_bias[g * 4 + i];
+        // MFMA tiles (16 pixels each): two per row (columns 0 .. 31) + the last column top to bottom.  Tile t = wave + 4 k of a
+        // wave is then row (wave >> 1) + 2 k, half (wave & 1): every LDS address is a per-lane constant plus a compile-time
+        // multiple of k -- no division, no address arithmetic per tile (a flat walk over the 33-wide rows cost ~ 20 vector
+        // instructions per tile for 2 MFMAs; this kernel is bound by those).  Only the last k mixes in the column tiles.
         // A tile is a chain LDS read -> two MFMAs -> SiLU -> LDS write; run one tile at a time it is the chain's LATENCY
         // that a wave spends (ablation: the reads alone were 57 of the kernel's 182 us per 64 frames), so the wave's
         // tiles go in batches: every fragment read of a batch is issued first, then its MFMAs, then its epilogues.
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const bool c0_inside = 2 * oy0 - 1 >= 0 && 2 * oy0 - 1 + C0H <= W0 && 2 * ox0 - 1 >= 0 && 2 * ox0 - 1 + C0W <= W0;   // no model.1 padding in this tile
+        constexpr int NROWT = 2 * C0H, NCOLT = (C0H + 15) / 16, NTILES = NROWT + NCOLT;
         constexpr int KT = (NTILES + 3) / 4;   // tiles per wave (the last one may not exist for the upper waves)
+        static_assert(C0W == 33 && NROWT % 4 == 2 && NCOLT <= 2, "row tiles end with waves 0, 1 of the last k; waves 2, 3 take the column tiles");
         constexpr int BT = 2;
+        const int row0 = wave_u >> 1, lx_r = 16 * (wave_u & 1) + r;      // row tiles: first row, this lane's column
+        // k slots without a tap (kernel row 3, tap slot 3) carry ZERO weights (engine.cpp packs them so), and s_in
+        // holds finite values only (pixels, padding, zeros; column INW of every row is finite): such a slot may read any
+        // pixel of the tile -- 0 x finite adds nothing -- so both halves of a fragment are ONE unpredicated 16-byte read
+        const half4 *rd_row[2] = {s_in + (2 * row0 + (g >> 1)) * INP + 2 * lx_r + 2 * (g & 1),     // k-step 0: kernel row g >> 1
+                                  s_in + (2 * row0 + 2) * INP + 2 * lx_r + 2 * (g & 1)};            // k-step 1: kernel row 2 (g < 2) / no tap (row 2 again)
+        half_t *st_row = s_c0 + (size_t)((row0 * 2 + (lx_r & 1)) * C0HALF + (lx_r >> 1)) * 16 + g * 4;
+        const int cx_row = 2 * ox0 - 1 + lx_r;
+        // column tiles (last k, waves 2 and 3): column C0W - 1, rows 16 (wave - 2) + r
+        const int ly_c = 16 * (wave_u - 2) + r;
+        const bool col_tile = wave_u >= 2, col_ok = col_tile && (unsigned)ly_c < (unsigned)C0H;
+        const int ly_cc = col_ok ? ly_c : 0;
+        const half4 *rd_col[2] = {s_in + (2 * ly_cc + (g >> 1)) * INP + 2 * (C0W - 1) + 2 * (g & 1),
+                                  s_in + (2 * ly_cc + 2) * INP + 2 * (C0W - 1) + 2 * (g & 1)};
+        half_t *st_col = s_c0 + (size_t)((ly_cc * 2 + ((C0W - 1) & 1)) * C0HALF + ((C0W - 1) >> 1)) * 16 + g * 4;
 #pragma unroll
         for (int k0 = 0; k0 < KT; k0 += BT) {
             half8 bf[BT][2];
             f32x4 acc[BT];
-            int lyv[BT], lxv[BT];
-            bool mvv[BT];
 #pragma unroll
             for (int k = 0; k < BT; k++) {
                 if (k0 + k >= KT) continue;
-                const int m = (wave_u + 4 * (k0 + k)) * 16 + r;
-                mvv[k] = m < NPX;
-                const int mm = mvv[k] ? m : 0;
-                lyv[k] = mm / C0W;
-                lxv[k] = mm - lyv[k] * C0W;
-                // k slots without a tap (kernel row 3, tap slot 3) carry ZERO weights (engine.cpp packs them so), and s_in
-                // holds finite values only (pixels, padding, zeros; column INW of every row is zero): such a slot may read any
-                // pixel of the tile -- 0 x finite adds nothing -- so both halves of a fragment are ONE unpredicated 16-byte read
+                const bool last = k0 + k == KT - 1;
 #pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    const int kh = s == 0 ? (g >> 1) : 2;          // k-step 1: kernel row 2 (g < 2) / no tap (row 2 again)
-                    bf[k][s] = *reinterpret_cast<const half8 *>(s_in + (2 * lyv[k] + kh) * INP + 2 * lxv[k] + 2 * (g & 1));
-                }
+                for (int s = 0; s < 2; s++)
+                    bf[k][s] = *reinterpret_cast<const half8 *>(last && col_tile ? rd_col[s] : rd_row[s] + (k0 + k) * (4 * INP));
             }
 #pragma unroll
             for (int k = 0; k < BT; k++) {
@@ -429,19 +438,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5
 #pragma unroll
             for (int k = 0; k < BT; k++) {
                 if (k0 + k >= KT) continue;
-                if (mvv[k]) {
-                    const int ly = lyv[k], lx = lxv[k];
-                    const int cy = 2 * oy0 - 1 + ly, cx = 2 * ox0 - 1 + lx;
-                    half4 o = z4;
-                    if (c0_inside || ((unsigned)cy < (unsigned)W0 && (unsigned)cx < (unsigned)W0)) {
+                const bool last = k0 + k == KT - 1;
+                const bool colt = last && col_tile;                       // (wave-uniform)
+                if (colt && !col_ok) continue;                            // rows past the tile (and wave 3 of the 4-row tile: no tile at all)
+                const int ly = colt ? ly_c : row0 + 2 * (k0 + k);
+                const int cy = 2 * oy0 - 1 + ly, cx = colt ? 2 * ox0 - 1 + (C0W - 1) : cx_row;
+                half4 o = z4;
+                if (c0_inside || ((unsigned)cy < (unsigned)W0 && (unsigned)cx < (unsigned)W0)) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const float v = acc[k][i] + bias0[i];
-                            o[i] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
-                        }
+                    for (int i = 0; i < 4; i++) {
+                        const float v = acc[k][i] + bias0[i];
+                        o[i] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
                     }
-                    *reinterpret_cast<half4 *>(s_c0 + (size_t)((ly * 2 + (lx & 1)) * C0HALF + (lx >> 1)) * 16 + g * 4) = o;
                 }
+                *reinterpret_cast<half4 *>(colt ? st_col : st_row + (size_t)(k0 + k) * (4 * C0HALF * 16)) = o;
             }
         }
     }
