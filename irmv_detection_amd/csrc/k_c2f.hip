@@ -34,6 +34,23 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 ld16(const half_t *p) { return *reinterpret_cast<const u32x4 *>(p); }
 __device__ __forceinline__ u32x4 keep_if(bool c, u32x4 v) { return c ? v : (u32x4){0u, 0u, 0u, 0u}; }
 __device__ __forceinline__ half8 as_h8(u32x4 v) { return __builtin_bit_cast(half8, v); }
+
+// MFMA tiles of an RH x RW pixel region (RW = 16 + 2 or 16 + 4): tile t < RH is columns 0 .. 15 of row t, the tiles after
+// those walk the remaining RW - 16 columns top to bottom, 16 pixels each.  Same tile count as a flat walk in runs of 16, but
+// a tile's row is the (wave-uniform) tile index: no division by the region width, and the 16 LDS reads of a fragment stay
+// inside one row of the plane (a flat run wraps rows: that was a third of these kernels' LDS bank conflicts).
+template <int RH, int RW>
+__device__ __forceinline__ bool region_tile_px(int t, int r, int &ly, int &lx)
+{
+    constexpr int LC = RW - 16;
+    static_assert(LC == 2 || LC == 4, "16 columns + a power of two");
+    if (t < RH) { ly = t; lx = r; return true; }
+    const int q = (t - RH) * 16 + r;
+    const bool ok = q < LC * RH;
+    ly = ok ? q / LC : 0;
+    lx = ok ? 16 + (q & (LC - 1)) : 0;
+    return ok;
+}
 }  // namespace
 
 __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
@@ -80,8 +97,8 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
 #pragma unroll
         for (int i = 0; i < NT1; i++) {
             const int t = wave + 4 * i;
-            const int m = (t < XN / 16 ? t : 0) * 16 + r;
-            const int ly = m / XW, lx = m - ly * XW;
+            int ly, lx;
+            (void)region_tile_px<XW, XW>(t < XN / 16 ? t : 0, r, ly, lx);
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
             const bool in = t < XN / 16 && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S;
             Bq[i] = ld16(xin + ((size_t)(in ? gy : 0) * S + (in ? gx : 0)) * a.x_ld + g * 8);   // zeroed (keep_if) where it is used: the select waits for the load
@@ -90,8 +107,9 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
         for (int i = 0; i < NT1; i++) {
             const int t = wave + 4 * i;
             if (t >= XN / 16) break;
-            const int m = t * 16 + r;
-            const int ly = m / XW, lx = m - ly * XW;
+            int ly, lx;
+            (void)region_tile_px<XW, XW>(t, r, ly, lx);      // (XN is a whole number of tiles: every lane has a pixel)
+            const int m = ly * XW + lx;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
             const half8 B = as_h8(keep_if((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S, Bq[i]));
             f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -132,10 +150,9 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
             toff[ks] = tap < 9 ? (kh * XW + kw) * HP + 16 * (g & 1) : -1;
         }
         for (int t = wave; t < (TN + 15) / 16; t += 4) {
-            const int m = t * 16 + r;
-            const bool mv = m < TN;
-            const int mm = mv ? m : 0;
-            const int ly = mm / TW, lx = mm - ly * TW;
+            int ly, lx;
+            const bool mv = region_tile_px<TW, TW>(t, r, ly, lx);
+            const int m = ly * TW + lx;
             const uint8_t *base = s_y1 + (ly * XW + lx) * HP;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -323,8 +340,8 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
         // the block input is read once per workgroup, straight into B fragments; the next tile's loads are in flight under
         // this tile's MFMAs and SiLU epilogue (a wave walks ~4 tiles: without this each would expose a full memory round trip)
         auto load_tile = [&](int t, u32x4 (&B)[KS1]) {
-            const int m = t * 16 + r;
-            const int ly = m / R1W, lx = m - ly * R1W;
+            int ly, lx;
+            (void)region_tile_px<R1H, R1W>(t, r, ly, lx);    // (R1N is a whole number of tiles: every lane has a pixel)
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
             const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             const int gyc = inside ? gy : 0, gxc = inside ? gx : 0;
@@ -339,18 +356,19 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
         u32x4 Bn[KS1];
         load_tile(wave, Bn);
         for (int t = wave; t < R1N / 16; t += 4) {
-            const int m = t * 16 + r;
-            const int ly = m / R1W, lx = m - ly * R1W;
+            int ly, lx;
+            (void)region_tile_px<R1H, R1W>(t, r, ly, lx);
+            const int m = ly * R1W + lx;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
             const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             half8 B[KS1];
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) B[ks] = as_h8(keep_if(inside, Bn[ks]));   // the select waits for the load: here, not at issue
             if (t + 4 < R1N / 16) load_tile(t + 4, Bn);
-            // y0 (output tiles 0, 1) is needed on the 8 x 16 tile only: a run of 16 region pixels that lies entirely in the halo
-            // rows (the region's first and last two: MFMA tiles 0, 1, 13, 14 of 15) computes y1 alone -- half the MFMAs and
-            // half the SiLUs of those tiles (the wave-uniform branch costs nothing; nothing of y0 was stored for them anyway)
-            const bool want_y0 = t * 16 + 15 >= 2 * R1W && t * 16 < (R1H - 2) * R1W;
+            // y0 (output tiles 0, 1) is needed on the 8 x 16 tile only: the row tiles of the region's first and last two rows
+            // (one per wave) compute y1 alone -- half the MFMAs and half the SiLUs of those tiles (the wave-uniform branch
+            // costs nothing; nothing of y0 was stored for them anyway)
+            const bool want_y0 = t >= R1H || (t >= 2 && t < R1H - 2);
             f32x4 acc[4];
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -440,10 +458,9 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
 #pragma unroll
         for (int i = 0; i < 8; i++) bias[i] = s_bias[g * 8 + i];
         for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : (R2N + 15) / 16); t += 4) {
-            const int m = t * 16 + r;
-            const bool mv = m < R2N;
-            const int mm = mv ? m : 0;
-            const int ly = mm / R2W, lx = mm - ly * R2W;
+            int ly, lx;
+            const bool mv = region_tile_px<R2H, R2W>(t, r, ly, lx);
+            const int m = ly * R2W + lx;
             const uint8_t *base = s_in + (ly * R1W + lx) * PS + g * 16;
             f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
