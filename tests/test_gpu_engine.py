@@ -763,6 +763,8 @@ def test_pipelined_slots_overlap_and_match_detect(blob):
     ((800, 600), 416, 1, True, False, True),
     ((1276, 1280), 640, 1, True, False, True),     # 2 : 1 columns behind ONE pad column: the direct tiles' column pairs start inside the tile (step -2)
     ((1276, 1280), 640, 1, False, True, True),     # ... and step +2
+    ((832, 832), 416, 0, True, False, True),       # 2 : 1 at a 416 net: the 8 x 16 direct tiles with a partial last tile column (104 = 6.5 x 16)
+    ((832, 600), 416, 1, False, True, True),       # ... with letterbox bands (rows 58 .. 357 have a source)
     ((641, 479), 640, 0, True, False, False),      # width not a multiple of 4: falls back to the three kernels
     ((4096, 3000), 640, 0, True, False, False),    # tile's source region larger than the LDS stage: falls back
 ])
