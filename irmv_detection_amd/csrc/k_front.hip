@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5
                 int gi = dg0 + sgn4 * pv[k];
                 if (EDGE) gi = min(max(gi, 0), a.sw - 4);                           // both columns without a source
                 const uint32_t xo = (uint32_t)(3 * gi);
-                const uint32_t *q0 = reinterpret_cast<const uint32_t *>(srcb + (uint32_t)tp[k].i0 * row_bytes + xo);
-                const uint32_t *q1 = reinterpret_cast<const uint32_t *>(srcb + (uint32_t)tp[k].i1 * row_bytes + xo);
+                const uint32_t *q0 = reinterpret_cast<const uint32_t *>(srcb + ((uint32_t)tp[k].i0 * row_bytes + xo));   // (one 32-bit offset: `p + a + b` is two 64-bit adds)
+                const uint32_t *q1 = reinterpret_cast<const uint32_t *>(srcb + ((uint32_t)tp[k].i1 * row_bytes + xo));
                 dd[k][0] = q0[0]; dd[k][1] = q0[1]; dd[k][2] = q0[2];
                 dd[k][3] = q1[0]; dd[k][4] = q1[1]; dd[k][5] = q1[2];
             }
