@@ -375,8 +375,10 @@ static int pack_conv(irmv_engine *e, const LayerW &l, Op &op)
                     packed[(((size_t)t * op.ksteps + ks) * 64 + lane) * 8 + j] = v;
                 }
             }
+    // SiLU layers compute on log2 e-scaled activations (irmv_common.hpp, "activation scale"): weights as they are, the bias
+    // scaled once here; layers without activation (the Detect finals) undo the scale in their epilogue and keep their bias
     std::vector<float> bias(op.cout_pad, 0.f);
-    for (int i = 0; i < l.cout; i++) bias[i] = l.b[i];
+    for (int i = 0; i < l.cout; i++) bias[i] = l.act == 1 ? (float)((double)l.b[i] * (double)kActScale) : l.b[i];
     int rc = dev_alloc(e, (void **)&op.w_packed, packed.size() * 2);
     if (rc) return rc;
     rc = dev_alloc(e, (void **)&op.bias, bias.size() * 4);
@@ -484,7 +486,11 @@ static int add_dw(irmv_engine *e, const std::string &layer, SegRef in, int Hin, 
     TRY(dev_alloc(e, (void **)&op.w_packed, w.size() * 2));
     TRY(dev_alloc(e, (void **)&op.bias, (size_t)l->cout * 4));
     HIP_TRY(hipMemcpy(op.w_packed, w.data(), w.size() * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(op.bias, l->b, (size_t)l->cout * 4, hipMemcpyHostToDevice));
+    {   // no activation, but the output feeds further layers: it stays at the activation scale, so the bias is scaled too
+        std::vector<float> bs((size_t)l->cout);
+        for (int i = 0; i < l->cout; i++) bs[i] = (float)((double)l->b[i] * (double)kActScale);
+        HIP_TRY(hipMemcpy(op.bias, bs.data(), bs.size() * 4, hipMemcpyHostToDevice));
+    }
     snprintf(op.kname, sizeof op.kname, "dwconv3x3s%d", l->stride);
     snprintf(op.kname_one, sizeof op.kname_one, "dwconv3x3s%d", l->stride);
     op.flops = 2.0 * op.Hout * op.Wout * (double)l->cout * 9;
@@ -771,7 +777,7 @@ static int build_engine(irmv_engine *e)
         // k = 32 s + 8 g + j  ->  kernel row kh = 2 s + (g >> 1), tap slot kw = 2 (g & 1) + (j >> 2), channel j & 3
         std::vector<uint16_t> w(2 * 64 * 8, 0);
         std::vector<float> b(16);
-        for (int o = 0; o < 16; o++) b[o] = l->b[o];
+        for (int o = 0; o < 16; o++) b[o] = (float)((double)l->b[o] * (double)kActScale);   // (irmv_common.hpp, "activation scale")
         for (int ks = 0; ks < 2; ks++)
             for (int lane = 0; lane < 64; lane++)
                 for (int j = 0; j < 8; j++) {
@@ -2251,7 +2257,9 @@ static int read_tensor_f32(irmv_engine *e, const Tensor &t, int slot, std::vecto
     } else {
         std::vector<uint16_t> h(t.slot_elems);
         HIP_TRY(hipMemcpy(h.data(), t.slot(slot), t.slot_elems * 2, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < t.slot_elems; i++) out[i] = half_bits_to_float(h[i]);
+        // activation tensors hold log2 e * a (irmv_common.hpp, "activation scale"); the network input does not
+        const float unscale = t.name == "input" ? 1.0f : kActUnscale;
+        for (size_t i = 0; i < t.slot_elems; i++) out[i] = half_bits_to_float(h[i]) * unscale;
     }
     return IRMV_OK;
 }

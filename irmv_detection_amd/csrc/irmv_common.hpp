@@ -12,6 +12,53 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- activation scale (round 4) ---------------------------------------------------
+// Every fp16 activation tensor between the layers holds a' = log2(e) * a.  With biases pre-multiplied by log2(e) at load
+// time (weights unchanged) a SiLU layer's accumulator is y = log2(e) * x, and
+//     log2(e) * x * sigmoid(x) = y * rcp(1 + exp2(-y)):
+// v_exp_f32 (with a free negate modifier), v_add, v_rcp, v_pk_mul, v_cvt_pk -- the v_mul in front of the exponential that
+// exp(-x) = exp2(-x * log2 e) costs per output value is gone, and so is the bias add (accumulators start AT the bias).
+// model.0 reads the unscaled image: its epilogue scales the accumulator (one fma, the bias rides in it); the Detect
+// finals (no activation, fp32 out) undo the scale the same way: out = acc * ln 2 + bias.  Read-backs of activation
+// tensors multiply by ln 2 on the host (engine.cpp read_tensor_f32).
+constexpr float kActScale = 1.44269504088896341f;    // log2(e)
+constexpr float kActUnscale = 0.693147180559945309f; // ln 2
+// Rounding is pinned by hand.  Left to the compiler, (half)(y * r) becomes v_pk_mul_f32 + v_cvt_pk_f16_f32 (two roundings)
+// where a lane's values pair up in registers and v_fma_mixlo/hi_f16 (the exact product rounded ONCE) where one is left
+// over -- which values those are differs from kernel to kernel, so two kernels computing the same layer disagreed in one
+// output of 70 000.  Every SiLU output is therefore produced by v_fma_mix*_f16 explicitly: exp, add, rcp, fma_mix -- four
+// vector instructions per output value, no separate multiply or convert -- and the shortcut variants (activation + residual,
+// rounded after the add) pin their fp32 intermediates with empty asm statements.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float silu_rcp(float y) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-y)); }
+// two activated outputs as one packed half2: lo = half(y0 * sigma(y0)), hi = half(y1 * sigma(y1)), each rounded once
+__device__ __forceinline__ unsigned int silu_pack2(float y0, float y1)
+{
+    const float r0 = silu_rcp(y0), r1 = silu_rcp(y1);
+    unsigned int o;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(o) : "v"(y0), "v"(r0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(o) : "v"(y1), "v"(r1));
+    return o;
+}
+__device__ __forceinline__ half8 silu_pack8(float y0, float y1, float y2, float y3, float y4, float y5, float y6, float y7)
+{
+    return __builtin_bit_cast(half8, (u32x4_t){silu_pack2(y0, y1), silu_pack2(y2, y3), silu_pack2(y4, y5), silu_pack2(y6, y7)});
+}
+__device__ __forceinline__ half4 silu_pack4(float y0, float y1, float y2, float y3)
+{
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(half4, (u32x2_t){silu_pack2(y0, y1), silu_pack2(y2, y3)});
+}
+// shortcut layers: half(round32(y * sigma(y)) + res), every intermediate rounded where it is written
+__device__ __forceinline__ half_t silu_add_res(float y, float res)
+{
+    float p = y * silu_rcp(y);
+    asm("" : "+v"(p));
+    float s = p + res;
+    asm("" : "+v"(s));
+    return (half_t)s;
+}
+
 constexpr int kHeadRec = 96;   // fp32 per anchor: box 64 | cls 16 (nc<=16) | kpt 16 (nk<=16)
 constexpr int kClsOff = 64;
 constexpr int kKptOff = 80;

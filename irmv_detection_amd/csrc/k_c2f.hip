@@ -24,7 +24,8 @@ constexpr int TW = T + 2, TN = TW * TW;   // bottleneck intermediate region (hal
 constexpr int HP = 32;                    // bytes per pixel of the 16-channel planes (16 consecutive pixels x 2 halves hit
                                           // 16 distinct 16-byte slots of a 256-byte window: conflict-free ds_read_b128)
 
-__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// SiLU on log2 e-scaled accumulators that START at the (scaled) bias, rounding pinned: irmv_common.hpp, "activation scale"
+__device__ __forceinline__ f32x4 bias4(const float *b) { return (f32x4){b[0], b[1], b[2], b[3]}; }
 
 // Global-memory B fragments are loaded UNCONDITIONALLY from a clamped (always valid) address and zeroed by a select
 // afterwards, as four dwords: behind `if (inside) B = load` the compiler builds the zero / loaded merge per 16-bit
@@ -112,17 +113,11 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
             const int m = ly * XW + lx;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
             const half8 B = as_h8(keep_if((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S, Bq[i]));
-            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            f32x4 acc0 = bias4(bias), acc1 = bias4(bias + 4);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[0], B, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[1], B, acc1, 0, 0, 0);
             half8 o = zero8;   // outside the image y1 is the bottleneck's zero padding
-            if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    o[i] = (half_t)silu(acc0[i] + bias[i]);
-                    o[4 + i] = (half_t)silu(acc1[i] + bias[4 + i]);
-                }
-            }
+            if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S) o = silu_pack8(acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3]);
             if (g >= 2) {
                 *reinterpret_cast<half8 *>(s_y1 + m * HP + (g - 2) * 16) = o;
             } else if ((unsigned)(ly - 2) < (unsigned)T && (unsigned)(lx - 2) < (unsigned)T) {
@@ -154,7 +149,7 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
             const bool mv = region_tile_px<TW, TW>(t, r, ly, lx);
             const int m = ly * TW + lx;
             const uint8_t *base = s_y1 + (ly * XW + lx) * HP;
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = bias4(bias);
 #pragma unroll
             for (int ks = 0; ks < 5; ks++) {
                 half8 B = zero8;
@@ -164,10 +159,7 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
             if (mv) {
                 const int gy = oy0 - 1 + ly, gx = ox0 - 1 + lx;
                 half4 o = (half4){0, 0, 0, 0};
-                if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) o[i] = (half_t)silu(acc[i] + bias[i]);
-                }
+                if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S) o = silu_pack4(acc[0], acc[1], acc[2], acc[3]);
                 *reinterpret_cast<half4 *>(s_t + m * HP + g * 8) = o;
             }
         }
@@ -189,7 +181,7 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
             const int m = t * 16 + r;
             const int ly = m / T, lx = m - ly * T;
             const uint8_t *base = s_t + (ly * TW + lx) * HP;
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = bias4(bias);
 #pragma unroll
             for (int ks = 0; ks < 5; ks++) {
                 half8 B = zero8;
@@ -199,12 +191,7 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
             const half4 rv = *reinterpret_cast<const half4 *>(s_y1 + ((ly + 2) * XW + lx + 2) * HP + g * 8);
             half4 o;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                // the unfused epilogue adds the shortcut behind a run-time branch, i.e. to the ROUNDED product: no fma here
-#pragma clang fp contract(off)
-                const float act = silu(acc[i] + bias[i]);
-                o[i] = (half_t)(act + (float)rv[i]);
-            }
+            for (int i = 0; i < 4; i++) o[i] = silu_add_res(acc[i], (float)rv[i]);   // the shortcut is added to the ROUNDED product, as in the per-layer kernel
             *reinterpret_cast<half4 *>(s_y2 + m * HP + g * 8) = o;
         }
     }
@@ -224,19 +211,14 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
                                    : *reinterpret_cast<const half8 *>(s_y1 + ((ly + 2) * XW + lx + 2) * HP + (g - 2) * 16);
             half8 B1 = zero8;
             if (g < 2) B1 = *reinterpret_cast<const half8 *>(s_y2 + m * HP + g * 16);
-            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            f32x4 acc0 = bias4(bias), acc1 = bias4(bias + 4);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc2[0][0], B0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc2[1][0], B0, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc2[0][1], B1, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc2[1][1], B1, acc1, 0, 0, 0);
             const int gy = oy0 + ly, gx = ox0 + lx;
             if (gy < S && gx < S) {
-                half8 o;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    o[i] = (half_t)silu(acc0[i] + bias[i]);
-                    o[4 + i] = (half_t)silu(acc1[i] + bias[4 + i]);
-                }
+                const half8 o = silu_pack8(acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3]);
                 *reinterpret_cast<half8 *>(out + ((size_t)gy * S + gx) * a.out_ld + g * 8) = o;
             }
         }
@@ -369,9 +351,9 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             // (one per wave) compute y1 alone -- half the MFMAs and half the SiLUs of those tiles (the wave-uniform branch
             // costs nothing; nothing of y0 was stored for them anyway)
             const bool want_y0 = t >= R1H || (t >= 2 && t < R1H - 2);
-            f32x4 acc[4];
+            f32x4 acc[4];   // tile 2 u + h starts at bias[u * 8 + 4 h ..]
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < 4; nt++) acc[nt] = bias4(bias + (nt >> 1) * 8 + (nt & 1) * 4);
             if (want_y0) {
 #pragma unroll
                 for (int ks = 0; ks < KS1; ks++)
@@ -388,10 +370,11 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             for (int u = 0; u < 2; u++) {
                 o[u] = zero8;   // outside the image y1 is the bottleneck's zero padding
                 if (inside && (u == 1 || want_y0)) {
+                    if (IRMV_ABL & 8) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        o[u][i] = (IRMV_ABL & 8) ? (half_t)(acc[2 * u][i] + bias[u * 8 + i]) : (half_t)silu(acc[2 * u][i] + bias[u * 8 + i]);
-                        o[u][4 + i] = (IRMV_ABL & 8) ? (half_t)(acc[2 * u + 1][i] + bias[u * 8 + 4 + i]) : (half_t)silu(acc[2 * u + 1][i] + bias[u * 8 + 4 + i]);
+                        for (int i = 0; i < 4; i++) { o[u][i] = (half_t)acc[2 * u][i]; o[u][4 + i] = (half_t)acc[2 * u + 1][i]; }
+                    } else {
+                        o[u] = silu_pack8(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3], acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]);
                     }
                 }
             }
@@ -462,7 +445,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             const bool mv = region_tile_px<R2H, R2W>(t, r, ly, lx);
             const int m = ly * R2W + lx;
             const uint8_t *base = s_in + (ly * R1W + lx) * PS + g * 16;
-            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            f32x4 acc0 = bias4(bias), acc1 = bias4(bias + 4);
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
                 const half8 B = *reinterpret_cast<const half8 *>(base + ((tap / 3) * R1W + (tap % 3)) * PS);
@@ -472,13 +455,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             if (mv) {
                 const int gy = oy0 - 1 + ly, gx = ox0 - 1 + lx;
                 half8 o = zero8;   // outside the image: the next conv's zero padding
-                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        o[i] = (half_t)silu(acc0[i] + bias[i]);
-                        o[4 + i] = (half_t)silu(acc1[i] + bias[4 + i]);
-                    }
-                }
+                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) o = silu_pack8(acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3]);
                 *reinterpret_cast<half8 *>(s_t + m * PS + g * 16) = o;
             }
         }
@@ -502,7 +479,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             const int m = t * 16 + r;
             const int ly = m / FW, lx = m - ly * FW;
             const uint8_t *base = s_t + (ly * R2W + lx) * PS + g * 16;
-            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            f32x4 acc0 = bias4(bias), acc1 = bias4(bias + 4);
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
                 const half8 B = *reinterpret_cast<const half8 *>(base + ((tap / 3) * R2W + (tap % 3)) * PS);
@@ -512,12 +489,11 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             half8 o;
             half8 rv = zero8;
             if constexpr (SHORTCUT) rv = *reinterpret_cast<const half8 *>(s_in + ((ly + 2) * R1W + lx + 2) * PS + g * 16);
+            if constexpr (SHORTCUT) {   // the per-layer epilogue adds the shortcut to the ROUNDED activation
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                // the per-layer epilogue adds the shortcut to the ROUNDED activation (separate statements): no fma here
-#pragma clang fp contract(off)
-                const float act = silu((i < 4 ? acc0[i] : acc1[i - 4]) + bias[i]);
-                o[i] = SHORTCUT ? (half_t)(act + (float)rv[i]) : (half_t)act;
+                for (int i = 0; i < 8; i++) o[i] = silu_add_res(i < 4 ? acc0[i] : acc1[i - 4], (float)rv[i]);
+            } else {
+                o = silu_pack8(acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3]);
             }
             if constexpr (MODE == 1) {
                 const int gy = oy0 + ly, gx = ox0 + lx;
@@ -566,7 +542,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             }
             f32x4 acc[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < 4; nt++) acc[nt] = bias4(bias + (nt >> 1) * 8 + (nt & 1) * 4);
 #pragma unroll
             for (int ks = 0; ks < KS2; ks++)
 #pragma unroll
@@ -574,12 +550,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
             if (inside) {
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    half8 o;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        o[i] = (half_t)silu(acc[2 * u][i] + bias[u * 8 + i]);
-                        o[4 + i] = (half_t)silu(acc[2 * u + 1][i] + bias[u * 8 + 4 + i]);
-                    }
+                    const half8 o = silu_pack8(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3], acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]);
                     *reinterpret_cast<half8 *>(out + ((size_t)gy * W + gx) * a.out_ld + u * 32 + g * 8) = o;
                 }
             }

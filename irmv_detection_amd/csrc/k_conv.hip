@@ -63,21 +63,20 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, int wg_x, int 
         bb[mt] = b;
     }
 
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     // bias of this lane's output channels, fetched with the first operands: read inside the epilogue it costs a memory
     // round trip per output block (a load after a store waits for the store: bias and output may alias for all the
-    // compiler knows)
+    // compiler knows).  SiLU layers: the accumulators START at the (log2 e-scaled) bias -- no add in the epilogue.
     f32x4 bs[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         const int t = nt0 + nt;
         bs[nt] = *reinterpret_cast<const f32x4 *>(a.bias + (a.pair ? ((t >> 1) * 32 + g * 8 + (t & 1) * 4) : (t * 16 + g * 4)));
     }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = ACT == 1 ? bs[nt] : (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const half8 *wp = reinterpret_cast<const half8 *>(a.w) + (size_t)nt0 * a.ksteps * 64 + lane;
     const int H0 = a.Hin >> a.s0.shift, W0 = a.Win >> a.s0.shift;
@@ -190,21 +189,20 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, int wg_x, int 
                     float vals[8];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        vals[i] = acc[mt][2 * u][i] + bs[2 * u][i];
-                        vals[4 + i] = acc[mt][2 * u + 1][i] + bs[2 * u + 1][i];
+                        vals[i] = ACT == 1 ? acc[mt][2 * u][i] : acc[mt][2 * u][i] * kActUnscale + bs[2 * u][i];
+                        vals[4 + i] = ACT == 1 ? acc[mt][2 * u + 1][i] : acc[mt][2 * u + 1][i] * kActUnscale + bs[2 * u + 1][i];
                     }
-                    if (ACT == 1) {
-#pragma unroll
-                        for (int i = 0; i < 8; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
-                    }
-                    if (a.res) {
+                    half8 o;   // (rounding pinned: irmv_common.hpp)
+                    if (ACT == 1 && a.res) {
                         const half8 rv = *reinterpret_cast<const half8 *>(a.res + m * a.res_ld + c0);
 #pragma unroll
-                        for (int i = 0; i < 8; i++) vals[i] += (float)rv[i];
-                    }
-                    half8 o;
+                        for (int i = 0; i < 8; i++) o[i] = silu_add_res(vals[i], (float)rv[i]);
+                    } else if (ACT == 1) {
+                        o = silu_pack8(vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], vals[6], vals[7]);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
+                        for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
+                    }
                     *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = o;
                 }
                 continue;
@@ -216,22 +214,23 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, int wg_x, int 
             const int c0 = a.pair ? ((t >> 1) * 32 + g * 8 + (t & 1) * 4) : (t * 16 + g * 4);
             float vals[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) vals[i] = acc[mt][nt][i] + bs[nt][i];
-            if (ACT == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
-            }
+            for (int i = 0; i < 4; i++) vals[i] = ACT == 1 ? acc[mt][nt][i] : acc[mt][nt][i] * kActUnscale + bs[nt][i];   // (no activation: the Detect finals -- undo the activation scale)
             if constexpr (OUT_F32) {
+                static_assert(ACT == 0, "fp32 outputs are the Detect finals: no activation");
                 *reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + m * a.out_ld + c0) =
                     (f32x4){vals[0], vals[1], vals[2], vals[3]};
             } else {
-                if (a.res) {
+                half4 o;   // (rounding pinned: irmv_common.hpp)
+                if (ACT == 1 && a.res) {
                     const half4 rv = *reinterpret_cast<const half4 *>(a.res + m * a.res_ld + c0);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) vals[i] += (float)rv[i];
+                    for (int i = 0; i < 4; i++) o[i] = silu_add_res(vals[i], (float)rv[i]);
+                } else if (ACT == 1) {
+                    o = silu_pack4(vals[0], vals[1], vals[2], vals[3]);
+                } else {
+                    o = (half4){(half_t)vals[0], (half_t)vals[1], (half_t)vals[2], (half_t)vals[3]};
                 }
-                *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) =
-                    (half4){(half_t)vals[0], (half_t)vals[1], (half_t)vals[2], (half_t)vals[3]};
+                *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = o;
             }
         }
     }
@@ -498,11 +497,11 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
 #pragma unroll
         for (int mt = 0; mt < MTA; mt++) { m_cur[mt] = (size_t)(ub + mt) * 16 + r; mv_cur[mt] = mv[mt]; }
         if constexpr (PRE) tile_ptrs(ub + MT);                   // from here p0 / p1 / mv describe the NEXT tile
-        f32x4 acc[MTA][NT];
+        f32x4 acc[MTA][NT];   // start at the bias: tile 2 u + h, register i <-> channel u * 32 + g * 8 + 4 h + i
 #pragma unroll
         for (int mt = 0; mt < MTA; mt++)
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){bias[nt >> 1][(nt & 1) * 4 + 0], bias[nt >> 1][(nt & 1) * 4 + 1], bias[nt >> 1][(nt & 1) * 4 + 2], bias[nt >> 1][(nt & 1) * 4 + 3]};
         // A fragments from LDS, double-buffered one k-step ahead; the scheduling barrier keeps the compiler from hoisting
         // all KS x NT fragment reads to the top of the unrolled loop (256 VGPRs and spills without it)
         half8 A[2][NT];
@@ -531,12 +530,10 @@ __global__ __launch_bounds__(256) void conv1x1_pw_kernel(ConvArgs a, int tiles_t
                 float vals[8];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    vals[i] = acc[mt][2 * u][i] + bias[u][i];
-                    vals[4 + i] = acc[mt][2 * u + 1][i] + bias[u][4 + i];
+                    vals[i] = acc[mt][2 * u][i];
+                    vals[4 + i] = acc[mt][2 * u + 1][i];
                 }
-                half8 o;
-#pragma unroll
-                for (int i = 0; i < 8; i++) o[i] = (half_t)(vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i])));
+                const half8 o = silu_pack8(vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], vals[6], vals[7]);
                 *reinterpret_cast<half8 *>(out + m_cur[mt] * a.out_ld + (nblk * 2 + u) * 32 + g * 8) = o;
             }
         }
@@ -626,11 +623,13 @@ __global__ __launch_bounds__(512) void conv1x1_pwn_kernel(ConvArgs a, int wg_per
 #pragma unroll
         for (int nb = 0; nb < NBW; nb++) {
             const half8 *s_wb = s_w + nb * (NT * KS * 64) + lane;
-            f32x4 acc[MTA][NT];
+            f32x4 acc[MTA][NT];   // start at the block's bias (LDS): tile 2 u + h, register i <-> channel u * 32 + g * 8 + 4 h + i
 #pragma unroll
-            for (int mt = 0; mt < MTA; mt++)
+            for (int nt = 0; nt < NT; nt++) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(s_bias + nb * 64 + (nt >> 1) * 32 + g * 8 + (nt & 1) * 4);
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int mt = 0; mt < MTA; mt++) acc[mt][nt] = b;
+            }
             half8 A[2][NT];
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) A[0][nt] = s_wb[(nt * KS) * 64];
@@ -648,13 +647,6 @@ __global__ __launch_bounds__(512) void conv1x1_pwn_kernel(ConvArgs a, int wg_per
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            float bias[2][8];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(s_bias + nb * 64 + u * 32 + g * 8), b1 = *reinterpret_cast<const f32x4 *>(s_bias + nb * 64 + u * 32 + g * 8 + 4);
-#pragma unroll
-                for (int i = 0; i < 4; i++) { bias[u][i] = b0[i]; bias[u][4 + i] = b1[i]; }
-            }
 #pragma unroll
             for (int mt = 0; mt < MTA; mt++) {
                 if (!mv_cur[mt]) continue;
@@ -663,12 +655,10 @@ __global__ __launch_bounds__(512) void conv1x1_pwn_kernel(ConvArgs a, int wg_per
                     float vals[8];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        vals[i] = acc[mt][2 * u][i] + bias[u][i];
-                        vals[4 + i] = acc[mt][2 * u + 1][i] + bias[u][4 + i];
+                        vals[i] = acc[mt][2 * u][i];
+                        vals[4 + i] = acc[mt][2 * u + 1][i];
                     }
-                    half8 o;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i] = (half_t)(vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i])));
+                    const half8 o = silu_pack8(vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], vals[6], vals[7]);
                     *reinterpret_cast<half8 *>(out + m_cur[mt] * a.out_ld + ((nblk0 + nb) * 2 + u) * 32 + g * 8) = o;
                 }
             }
@@ -946,13 +936,19 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     // staged ONCE and every image's patch of that chunk runs against them (image-major order re-stages the 9 NT KiB of
     // weights per (image, chunk) step: for the small tiles that is more LDS traffic than the patch itself)
     constexpr int NA = CM > 0 ? CM : 1;
+    // Accumulators start AT the bias (log2 e-scaled, irmv_common.hpp): fetched from memory here -- s_bias is not visible
+    // before the first barrier --, and put back from the epilogue's own copy at the end of every image (store_tile), where
+    // the zero fill used to be: the bias add of the epilogue is gone at no cost.
     f32x4 acc[NA][MT][NT];
 #pragma unroll
-    for (int ai = 0; ai < NA; ai++)
+    for (int nt = 0; nt < NT; nt++) {
+        const int ch = (NT % 2 == 0) ? (by * NT * 16 + (nt >> 1) * 32 + g * 8 + (nt & 1) * 4) : (a.pair ? ((by >> 1) * 32 + g * 8 + (by & 1) * 4) : (by * 16 + g * 4));
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.bias + ch);
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int ai = 0; ai < NA; ai++)
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[ai][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int mt = 0; mt < MT; mt++) acc[ai][mt][nt] = b0;
+    }
 
     // epilogue of one image (bias, SiLU, shortcut, fp16, NHWC store); clears the accumulators for the next one
     const int nt0 = nblk * NT;
@@ -1009,17 +1005,18 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
                         float vals[8];
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            vals[i] = accx[mt][2 * u][i] + bs[u][i];
-                            vals[4 + i] = accx[mt][2 * u + 1][i] + bs[u][4 + i];
+                            vals[i] = accx[mt][2 * u][i];
+                            vals[4 + i] = accx[mt][2 * u + 1][i];
                         }
+                        if (IRMV_ABL & 8) {
 #pragma unroll
-                        for (int i = 0; i < 8; i++) if (!(IRMV_ABL & 8)) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
-                        if (a.res) {
+                            for (int i = 0; i < 8; i++) ov[u][i] = (half_t)vals[i];
+                        } else if (a.res) {   // (rounding pinned: irmv_common.hpp)
 #pragma unroll
-                            for (int i = 0; i < 8; i++) vals[i] += (float)rv8[mt][u][i];
+                            for (int i = 0; i < 8; i++) ov[u][i] = silu_add_res(vals[i], (float)rv8[mt][u][i]);
+                        } else {
+                            ov[u] = silu_pack8(vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], vals[6], vals[7]);
                         }
-#pragma unroll
-                        for (int i = 0; i < 8; i++) ov[u][i] = (half_t)vals[i];
                         if constexpr (N2 == 0) if (!(IRMV_ABL & 16) || ov[u][0] == (half_t)123.0f) *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = ov[u];
                     }
                     if constexpr (N2 > 0) {
@@ -1033,7 +1030,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
                             c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[t2][1], ov[1], c2, 0, 0, 0);
                             const int co = t2 * 16 + g * 4;
                             const f32x4 b2 = *reinterpret_cast<const f32x4 *>(s_bias2 + co);
-                            const f32x4 v2 = (f32x4){c2[0] + b2[0], c2[1] + b2[1], c2[2] + b2[2], c2[3] + b2[3]};
+                            const f32x4 v2 = (f32x4){c2[0] * kActUnscale + b2[0], c2[1] * kActUnscale + b2[1], c2[2] * kActUnscale + b2[2], c2[3] * kActUnscale + b2[3]};   // (the 1x1's inputs carry the activation scale)
                             if (mv[mt]) *reinterpret_cast<f32x4 *>(a.out2 + m * a.out2_ld + co) = v2;
                             if (a.scan_keys) {
                                 // class logits: lane (g, r) holds classes co .. co + 3 of its pixel -- the values the head record just
@@ -1062,22 +1059,20 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
                 } else {
                     const int t = nt0;
                     const int c0 = a.pair ? ((t >> 1) * 32 + g * 8 + (t & 1) * 4) : (t * 16 + g * 4);
-                    float vals[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        vals[i] = accx[mt][0][i] + bs[0][i];
-                        vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
-                    }
+                    half4 o;
                     if (a.res) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) vals[i] += (float)rv4[mt][i];
+                        for (int i = 0; i < 4; i++) o[i] = silu_add_res(accx[mt][0][i], (float)rv4[mt][i]);
+                    } else {
+                        o = silu_pack4(accx[mt][0][0], accx[mt][0][1], accx[mt][0][2], accx[mt][0][3]);
                     }
-                    *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) =
-                        (half4){(half_t)vals[0], (half_t)vals[1], (half_t)vals[2], (half_t)vals[3]};
+                    *reinterpret_cast<half4 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = o;
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) accx[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; nt++)   // the next image starts at the bias again
+                accx[mt][nt] = (NT % 2 == 0) ? (f32x4){bs[nt >> 1][(nt & 1) * 4 + 0], bs[nt >> 1][(nt & 1) * 4 + 1], bs[nt >> 1][(nt & 1) * 4 + 2], bs[nt >> 1][(nt & 1) * 4 + 3]}
+                                             : (f32x4){bs[0][0], bs[0][1], bs[0][2], bs[0][3]};
         }
     };
 
@@ -1282,7 +1277,13 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         if constexpr (PP) {
             // group 1 runs one barrier (= half a step) behind group 0; both execute 2 nimg + 2 barriers
             issue_wr(0);
-            if (sub == 1) __builtin_amdgcn_s_barrier();
+            if (sub == 1) {
+                // group 0 passes this barrier through its __syncthreads below and then reads weight / bias / fused-1x1
+                // pieces that THIS group's threads wrote to LDS above: their ds_writes must have landed before the
+                // barrier releases (a bare s_barrier carries no lgkmcnt wait on gfx950)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_barrier();
+            }
             write_wr();
             if (nimg > 1) issue_wr(1);
             __syncthreads();

@@ -445,11 +445,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5
                 const int cy = 2 * oy0 - 1 + ly, cx = colt ? 2 * ox0 - 1 + (C0W - 1) : cx_row;
                 half4 o = z4;
                 if (c0_inside || ((unsigned)cy < (unsigned)W0 && (unsigned)cx < (unsigned)W0)) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const float v = acc[k][i] + bias0[i];
-                        o[i] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
-                    }
+                    // model.0 reads the UNSCALED image: one fma brings the accumulator to the activation scale (bias0 = log2 e * b)
+                    o = silu_pack4(__builtin_fmaf(acc[k][0], kActScale, bias0[0]), __builtin_fmaf(acc[k][1], kActScale, bias0[1]),
+                                   __builtin_fmaf(acc[k][2], kActScale, bias0[2]), __builtin_fmaf(acc[k][3], kActScale, bias0[3]));
                 }
                 *reinterpret_cast<half4 *>(colt ? st_col : st_row + (size_t)(k0 + k) * (4 * C0HALF * 16)) = o;
             }
@@ -461,11 +459,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5
 
     // ---- C: model.1.conv: 8 x 16 outputs x 32 channels; Cin = 16, so a k-step of 32 spans two taps ----
     {
+        float bias1[8];   // lane g holds channels g*8 + [0, 8): tile nt starts at bias1[4 nt ..] (accumulators start at the bias)
+#pragma unroll
+        for (int i = 0; i < 8; i++) bias1[i] = s_bias[16 + g * 8 + i];
         f32x4 acc[MTC][2];
 #pragma unroll
         for (int mt = 0; mt < MTC; mt++)
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < 2; nt++) acc[mt][nt] = (f32x4){bias1[4 * nt], bias1[4 * nt + 1], bias1[4 * nt + 2], bias1[4 * nt + 3]};
         const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < 5; ks++) {
@@ -489,9 +490,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5
         // epilogue of the direct kernel's paired-tile path: lane g holds channels g*8 + [0, 8)
         const int ox = ox0 + r;
         if (ox < W1) {
-            float bias1[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) bias1[i] = s_bias[16 + g * 8 + i];
 #pragma unroll
             for (int mt = 0; mt < MTC; mt++) {
                 const int oy = oy0 + MTC * wave + mt;
@@ -499,14 +497,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5
                 float vals[8];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    vals[i] = acc[mt][0][i] + bias1[i];
-                    vals[4 + i] = acc[mt][1][i] + bias1[4 + i];
+                    vals[i] = acc[mt][0][i];
+                    vals[4 + i] = acc[mt][1][i];
                 }
-#pragma unroll
-                for (int i = 0; i < 8; i++) vals[i] = vals[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-vals[i]));
-                half8 o;
-#pragma unroll
-                for (int i = 0; i < 8; i++) o[i] = (half_t)vals[i];
+                const half8 o = silu_pack8(vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], vals[6], vals[7]);
                 *reinterpret_cast<half8 *>(a.out + ((size_t)(b * W1 + oy) * W1 + ox) * a.out_ld + g * 8) = o;
             }
         }

@@ -135,12 +135,9 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a)
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, bf[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, bf[1], acc, 0, 0, 0);
         if (mv) {
-            half4 o;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float v = acc[i] + a.b[g * 4 + i];
-                o[i] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
-            }
+            // the image is unscaled: one fma brings the accumulator to the activation scale (a.b = log2 e * bias; irmv_common.hpp)
+            const half4 o = silu_pack4(__builtin_fmaf(acc[0], kActScale, a.b[g * 4 + 0]), __builtin_fmaf(acc[1], kActScale, a.b[g * 4 + 1]),
+                                       __builtin_fmaf(acc[2], kActScale, a.b[g * 4 + 2]), __builtin_fmaf(acc[3], kActScale, a.b[g * 4 + 3]));
             *reinterpret_cast<half4 *>(a.y + (size_t)mm * 16 + g * 4) = o;
         }
     }

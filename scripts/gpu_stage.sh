@@ -20,6 +20,7 @@ run() {   # run <name> <timeout s> <cmd...>
 for st in "$@"; do
 case $st in
 tests)   run gpu_tests 900 python3 -m pytest tests -m gpu -x -q -rA --durations=15 ;;
+testsall) run gpu_tests 1000 python3 -m pytest tests -m gpu -q -rA --durations=15 ;;
 tests_k) run gpu_tests_k 600 python3 -m pytest tests -m gpu -x -q -rA -k "$TESTS_K" ;;
 smoke)   run smoke 300 python3 __graft_entry__.py smoke ;;
 layers)  SLOTS=64 run layers64 300 python3 scripts/prof_layers.py
@@ -146,7 +147,7 @@ repro)   # the round-1 fault sequence, ONCE, under the profiler that exposed it,
          cd /tmp; export TMPDIR=/tmp
          IRMV_LOG_ALLOC=1 run repro_prof 300 rocprofv3 --kernel-trace --output-format csv -d $O/repro_prof -- python3 $R/scripts/probe.py repro
          cd $R ;;
-*)       run "custom_$st" 600 bash -c "$st" ;;
+*)       run "custom_$(echo "$st" | tr -c 'A-Za-z0-9_.\n' '_' | cut -c1-40)" 900 bash -c "$st" ;;
 esac
 done
 echo "=== all stages done" | tee -a $O/stages.log
