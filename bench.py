@@ -46,13 +46,40 @@ PEAK_FP16_TFLOPS = 2500.0      # dense fp16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
 
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round NN, or None."""
+    import re
+    best = None
+    for name in os.listdir(os.path.join(ROOT, "profiles")):
+        m = re.fullmatch(r"r(\d+)_" + re.escape(suffix), name)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), name)
+    return os.path.join(ROOT, "profiles", best[1]) if best else None
+
+
 def tune_cache_seed():
     """Committed autotuner table the bench (and the test of the benchmarked configuration) replays: newest round first."""
-    for name in ("r03_tune_cache.txt", "r02_tune_cache.txt", "r01_tune_cache.txt"):
-        p = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(p):
-            return p
-    return None
+    return newest_profile("tune_cache.txt")
+
+
+def load_counter_file(suffix):
+    """-> (data or None, 'profiles/<name>' or None, note).  The counter files (MFMA busy cycles, HBM traffic, the concurrent
+    replay's launch times) come from separate rocprofv3 passes (scripts/gpu_stage.sh profiles), not from this run: each
+    carries the hash of the kernel sources + flags it was collected on (scripts/build_stamp.py), and a file that describes
+    another build is NOT reported -- the fields it would feed are null and say why."""
+    path = newest_profile(suffix)
+    if not path:
+        return None, None, "no such file under profiles/"
+    rel = "profiles/" + os.path.basename(path)
+    with open(path) as f:
+        data = json.load(f)
+    from irmv_detection_amd import _build
+    stamp = data.get("build") or data.get("_build") or {}
+    if not stamp.get("src_sha256"):
+        return None, rel, f"{rel} carries no build stamp: not reported"
+    if stamp["src_sha256"] != _build.source_hash():
+        return None, rel, f"{rel} was collected on other kernel sources (src_sha256 {stamp['src_sha256'][:12]} != {_build.source_hash()[:12]}): not reported"
+    return data, rel, f"{rel}: separate rocprofv3 pass on this build (src_sha256 {stamp['src_sha256'][:12]}), not measured in this run"
 
 
 def spawn_ranks(n):
@@ -195,6 +222,9 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dev_idx = R.device
+    # this rank fills its GPU's pinned slots and submits its steps: it runs on the CPUs of that GPU's own socket, and the
+    # engine allocates the slots there (include/irmv_hip.h, "NUMA placement"; nothing is bound where the box reports no node)
+    numa_bound = capi.numa_bind_to_device(dev_idx) if os.environ.get("IRMV_NUMA", "1") != "0" else -1
 
     def device_sync():
         """hipDeviceSynchronize on this rank's GPU, through the C ABI."""
@@ -206,14 +236,28 @@ def main():
     blob = make_blob(args) if rank == 0 else None
     backbone = arch.BACKBONE_SHUFFLE if args.model == "shufflenet" else arch.BACKBONE_C2F
     bc = R.broadcast_blob(blob) if world > 1 else None    # device buffer owned by the communicator, alive until R.close()
-    weights_via = "one RCCL broadcast from rank 0 (libirmv_comm.so)" if bc else ("generated in process" if world == 1 else
-                  "RCCL NOT AVAILABLE on this node: every rank generated the same seeded blob; barriers and clocks through files")
+    rccl_used = bool(bc) and backend == "rccl"        # the weight broadcast ran over RCCL through libirmv_comm.so
+    if bc:
+        weights_via = ("one RCCL broadcast from rank 0 (libirmv_comm.so)" if backend == "rccl" else
+                       f"one broadcast from rank 0 through torch.distributed ({backend}; rehearsal plumbing, not libirmv_comm.so)")
+    else:
+        weights_via = ("generated in process" if world == 1 else
+                       "RCCL NOT AVAILABLE on this node: every rank generated the same seeded blob; barriers and clocks through files")
     if bc:
         eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_device_ptr=bc[0], weights_bytes=bc[1], num_slots=B, net_size=args.net)
     else:
         if blob is None:
             blob = make_blob(args)
         eng = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=blob, num_slots=B, net_size=args.net)
+
+    # host-side placement of every rank (all ranks take part in the reductions)
+    def gather_int(v):
+        return [int(round(R.sum_over_ranks(float(v) if rank == r else 0.0))) for r in range(world)] if world > 1 else [int(v)]
+    numa_info = dict(device_node=gather_int(eng.numa_node), slots_placed=gather_int(1 if eng.numa_placed else 0),
+                     rank_thread_bound_to=gather_int(numa_bound),
+                     note="per GPU: host NUMA node closest to the device (hipDeviceAttributeHostNumaId; -1 = the box reports none), whether the pinned "
+                          "frame slots were allocated and first touched under that node's CPU set and memory policy, and the node this rank's "
+                          "thread was bound to before it created the engine (-1 = not bound)")
 
     # this rank's frames: round-robin over the global frame index, made resident in HBM once
     my = irmv_comm.shard_frames(B * world, rank, world)
@@ -308,41 +352,31 @@ def main():
         conv_fl = sum(v["flops"] for k, v in agg.items() if v["flops"] > 0) / len(prof_runs)
         pre_name = "preprocess" if "preprocess" in agg else "front_fused"   # fused: preprocess + model.0 + model.1 in one kernel
         pre = agg.get(pre_name)
-        # HBM traffic of that kernel from the separate rocprofv3 --pmc passes (scripts/collect_traffic.py), if collected
+        # HBM traffic of that kernel from the separate rocprofv3 --pmc passes (scripts/collect_traffic.py), if collected ON
+        # THIS BUILD (load_counter_file: the newest round's file, dropped when its build stamp is another tree's)
         traffic = None
         import re
         def prof_name(n):   # bench name -> the name the profile reducers give the kernel symbol (launch-time options dropped)
             return re.sub(r"_i\d+|_cm|_w8|_p2", "", n)
         base_name = prof_name(dom_name)
         default_cfg = (args.model, args.net, args.int8) == ("yolov8n", 640, False) and per_graph == 128   # what the counter files were collected on: 128-frame graphs
-        for tname in (("r03_traffic.json", "r02_traffic.json", "r01_traffic.json") if default_cfg else ()):
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath):
-                with open(tpath) as tf:
-                    traffic = (json.load(tf).get(base_name) or {}).get("hbm_bytes_per_launch")
-                break
+        not_default = "counter files are collected on the default configuration (yolov8n, 640, 128-frame graphs): not reported"
+        tdata, tsrc, tnote = load_counter_file("traffic.json") if default_cfg else (None, None, not_default)
+        if tdata:
+            traffic = (tdata.get(base_name) or {}).get("hbm_bytes_per_launch")
         # in-kernel MFMA utilisation of the conv kernels from the separate rocprofv3 --pmc pass (scripts/collect_mfma.py)
-        mfma, mpath = None, None
-        for mname in (("r03_mfma.json", "r02_mfma.json") if default_cfg else ()):
-            mpath = os.path.join(ROOT, "profiles", mname)
-            if os.path.exists(mpath):
-                with open(mpath) as mf:
-                    mfma = json.load(mf)
-                break
-        # the same launches inside the BENCHMARKED replay (three graphs sharing the chip): rocprofv3 --kernel-trace --stats of
+        mfma, msrc, mnote = load_counter_file("mfma.json") if default_cfg else (None, None, not_default)
+        # the same launches inside the BENCHMARKED replay (the graphs sharing the chip): rocprofv3 --kernel-trace --stats of
         # bench.py itself, reduced by scripts/collect_concurrent.py
-        conc = None
-        cpath = os.path.join(ROOT, "profiles", "r03_concurrent.json")
-        if default_cfg and os.path.exists(cpath):
-            with open(cpath) as cf:
-                conc = json.load(cf).get("kernels")
+        cdata, csrc, cnote = load_counter_file("concurrent.json") if default_cfg else (None, None, not_default)
+        conc = cdata.get("kernels") if cdata else None
         if ai >= ridge:
             roofline = dict(bound="mfma", achieved=round(tflops, 3), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                             frac=round(tflops / PEAK_FP16_TFLOPS, 5))
         else:
             roofline = dict(bound="hbm", achieved=round(gbs_dom, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=round(gbs_dom / PEAK_HBM_GBS, 5))
-        roofline.update(traffic=traffic, kernel=dom_name, launches_per_step=dom["n"] // len(prof_runs),
+        roofline.update(traffic=traffic, traffic_source=tnote, kernel=dom_name, launches_per_step=dom["n"] // len(prof_runs),
                         avg_launch_ms=round(avg_ms, 5), algorithmic_bytes_per_launch=round(dom["bytes"] / dom["n"]),
                         algorithmic_flops_per_launch=round(dom["flops"] / dom["n"]), arithmetic_intensity=round(ai, 1),
                         kernel_tflops=round(tflops, 3), kernel_gbs=round(gbs_dom, 1),
@@ -360,9 +394,11 @@ def main():
                             frac=round(k_tf / PEAK_FP16_TFLOPS if k_ai >= ridge else k_gb / PEAK_HBM_GBS, 4),
                             tflops=round(k_tf, 1), gbs=round(k_gb, 1)))
         roofline["top_kernels"] = top
-        if mfma:
-            roofline["mfma_util"] = mfma.get("conv_mfma_util")
-            roofline["mfma_util_source"] = f"profiles/{os.path.basename(mpath)} (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES over the conv kernels)"
+        roofline["mfma_util"] = mfma.get("conv_mfma_util") if mfma else None
+        roofline["mfma_util_source"] = mnote + (" (sum of SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) over the conv kernels)" if mfma else "")
+        roofline["concurrent_source"] = cnote
+        if not conc:
+            roofline["avg_launch_ms_concurrent"] = roofline["frac_concurrent"] = roofline["dominant_concurrent"] = None
         if conc:
             # the dominant kernel's launches as the benchmarked replay runs them, and which symbol dominates THAT replay
             c_dom = conc.get(base_name)
@@ -371,7 +407,7 @@ def main():
                 roofline["frac_concurrent"] = round((tflops / PEAK_FP16_TFLOPS if ai >= ridge else gbs_dom / PEAK_HBM_GBS) * avg_ms / c_dom["avg_launch_ms"], 5)
             ck, cv = max(conc.items(), key=lambda kv: kv[1]["share_of_kernel_time"])
             roofline["dominant_concurrent"] = dict(kernel=ck, share_of_kernel_time=cv["share_of_kernel_time"], avg_launch_ms=cv["avg_launch_ms"],
-                                                   source="profiles/r03_concurrent.json (rocprofv3 --kernel-trace --stats of this bench: the concurrently replayed graphs sharing the chip)")
+                                                   source=f"{csrc} (rocprofv3 --kernel-trace --stats of this bench: the concurrently replayed graphs sharing the chip; not measured in this run)")
             for t in top:
                 ct = conc.get(prof_name(t["kernel"]))
                 if ct:
@@ -386,6 +422,11 @@ def main():
             "value": round(fps, 1), "value_hbm_resident": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "rccl": rccl_used,
+            "rccl_note": ("weights reached every rank through ncclBroadcast (libirmv_comm.so)" if rccl_used else
+                          ("one rank: nothing to broadcast; a multi-rank RCCL broadcast has not run on hardware yet (every GPU box so far had one MI355X)" if world == 1
+                           else "NO RCCL in this run: see config.weights")),
+            "numa_node": numa_info["device_node"], "numa": numa_info,
             "config": {"workload": f"synthetic {sw}x{sh} u8 camera frames resident in HBM -> {args.net}x{args.net} "
                                    + ("YOLOv8n" if args.model == "yolov8n" else "YOLOv8n with ShuffleNetV2 backbone stages") +
                                    f" (nc=14, 4-kpt head, seeded {'int8-container weights expanded to fp16 at load: int8 storage / broadcast, fp16 compute' if args.int8 else 'fp16 weights'}) -> decode+NMS -> IPPE PnP; "
@@ -494,6 +535,44 @@ def main():
                                harness_ms=dict(avg=round(float(np.mean(runs)), 4), max=round(float(np.max(runs)), 4), min=round(float(np.min(runs)), 4)),
                                median_frame=mid, frames=sorted(per_frame, key=lambda d: d["frame"]))
         ceng.close()
+
+    if rank == 0 and world == 1 and "config4" not in skip and (args.model, args.net, args.int8) == ("yolov8n", 640, False):
+        # BASELINE configs[4] through the driver's eyes: a short leg of the ShuffleNetV2-backbone variant (int8-container weights
+        # expanded to fp16 at load, 416 x 416 net), NOT the configuration the metric is quoted on -- value + the dominant
+        # kernel's roofline fraction only; `python bench.py --model shufflenet --net 416 --int8` is the full line
+        dbg("config4")
+        import copy
+        a4 = copy.copy(args); a4.model, a4.net, a4.int8 = "shufflenet", 416, True
+        B4, steps4 = 192, 5
+        e4 = YoloEngine(None, (sw, sh), device=dev_idx, weights_blob=make_blob(a4), num_slots=B4, net_size=416)
+        for s4 in range(B4):
+            e4.get_src_image_buffer(s4)[:] = frames_u8[s4 % len(frames_u8)]
+        e4.submit(0, B4, h2d=True); e4.wait()
+        for _ in range(2):
+            e4.submit(0, B4, h2d=False)
+        e4.wait()
+        device_sync()
+        t4 = time.perf_counter()
+        for _ in range(steps4):
+            e4.submit(0, B4, h2d=False)
+        e4.wait()
+        device_sync()
+        dt4 = time.perf_counter() - t4
+        pg4 = (B4 + e4.num_streams - 1) // e4.num_streams
+        agg4 = {}
+        for run in [e4.profile(0, pg4) for _ in range(3)][1:]:
+            for st in run:
+                a = agg4.setdefault(st["name"], dict(ms=0.0, flops=0.0, bytes=0.0))
+                a["ms"] += st["ms"]; a["flops"] += st["flops"]; a["bytes"] += st["bytes"]
+        k4, v4 = max(((k, v) for k, v in agg4.items() if v["bytes"] > 0), key=lambda kv: kv[1]["ms"])
+        ai4 = v4["flops"] / v4["bytes"]
+        ridge4 = PEAK_FP16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        frac4 = (v4["flops"] / (v4["ms"] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS) if ai4 >= ridge4 else (v4["bytes"] / (v4["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS)
+        late["config4"] = dict(workload=f"BASELINE configs[4] family: {sw}x{sh} frames resident in HBM -> 416x416 YOLOv8n with ShuffleNetV2 backbone stages (stand-in architecture, "
+                                        f"parity unpinned), int8-container weights expanded to fp16 at load; {B4} frames per step as {e4.num_streams} graphs; NOT the metric's configuration",
+                               value=round(B4 * steps4 / dt4, 1), unit="frames/s", steps=steps4, ms_per_step=round(dt4 / steps4 * 1e3, 4),
+                               roofline=dict(kernel=k4, bound="mfma" if ai4 >= ridge4 else "hbm", frac=round(frac4, 5), arithmetic_intensity=round(ai4, 1)))
+        e4.close()
 
     if out is not None:
         out.update(late)

@@ -26,6 +26,9 @@
 
 #include "irmv_detection/armor.hpp"
 #include "irmv_detection/cv_compat.hpp"
+#if IRMV_HAVE_OPENCV
+#include <opencv2/imgproc.hpp>   // cv::rectangle, cv::putText (visualize_bboxes)
+#endif
 #include "irmv_hip.h"
 
 namespace irmv_detection
@@ -163,8 +166,18 @@ public:
       return;
     }
     for (const auto & b : bboxes) {
-      const bool blue = armor_class_name(b.class_id)[0] == 'B';
+      const std::string name(armor_class_name(b.class_id));
+      const bool blue = name[0] == 'B';
+#if IRMV_HAVE_OPENCV
+      // the reference's own calls (src/yolo_engine.cpp:229-241)
+      const cv::Point p1(int(b.xyxy[0]), int(b.xyxy[1])), p2(int(b.xyxy[2]), int(b.xyxy[3]));
+      const cv::Scalar color = blue ? cv::Scalar(0, 0, 255) : cv::Scalar(255, 0, 0);
+      cv::rectangle(image, p1, p2, color, 2);
+      cv::putText(image, name, p1, cv::FONT_HERSHEY_SIMPLEX, 1, color, 2);
+#else
       draw_rect(image, int(b.xyxy[0]), int(b.xyxy[1]), int(b.xyxy[2]), int(b.xyxy[3]), blue ? 0 : 255, 0, blue ? 255 : 0);
+      draw_label(image, name, int(b.xyxy[0]), int(b.xyxy[1]), blue ? 0 : 255, 0, blue ? 255 : 0);
+#endif
     }
   }
 
@@ -193,6 +206,43 @@ private:
     for (int t = 0; t < 2; t++) {
       for (int x = x1; x <= x2; x++) { put(x, y1 + t); put(x, y2 - t); }
       for (int y = y1; y <= y2; y++) { put(x1 + t, y); put(x2 - t, y); }
+    }
+  }
+
+  // Class label without OpenCV: the ArmorClass names (B1..B5, BO, BS, R1..R5, RO, RS, UNKNOWN) in a 5 x 7 bitmap font at
+  // scale 3 (glyphs 15 x 21 px, 18 px advance: the size of FONT_HERSHEY_SIMPLEX at scale 1), text origin = bottom-left
+  // corner at (x, y) like cv::putText (src/yolo_engine.cpp:238-241).
+  static const uint8_t * glyph(char c)
+  {
+    static const uint8_t font[][8] = {
+      {'B', 0x1e, 0x11, 0x11, 0x1e, 0x11, 0x11, 0x1e}, {'R', 0x1e, 0x11, 0x11, 0x1e, 0x14, 0x12, 0x11},
+      {'O', 0x0e, 0x11, 0x11, 0x11, 0x11, 0x11, 0x0e}, {'S', 0x0f, 0x10, 0x10, 0x0e, 0x01, 0x01, 0x1e},
+      {'U', 0x11, 0x11, 0x11, 0x11, 0x11, 0x11, 0x0e}, {'N', 0x11, 0x19, 0x15, 0x13, 0x11, 0x11, 0x11},
+      {'K', 0x11, 0x12, 0x14, 0x18, 0x14, 0x12, 0x11}, {'W', 0x11, 0x11, 0x11, 0x15, 0x15, 0x1b, 0x11},
+      {'1', 0x04, 0x0c, 0x04, 0x04, 0x04, 0x04, 0x0e}, {'2', 0x0e, 0x11, 0x01, 0x02, 0x04, 0x08, 0x1f},
+      {'3', 0x1e, 0x01, 0x01, 0x0e, 0x01, 0x01, 0x1e}, {'4', 0x02, 0x06, 0x0a, 0x12, 0x1f, 0x02, 0x02},
+      {'5', 0x1f, 0x10, 0x1e, 0x01, 0x01, 0x11, 0x0e}};
+    for (const auto & g : font)
+      if (g[0] == uint8_t(c)) return g + 1;
+    return nullptr;
+  }
+  static void draw_label(cv::Mat & img, const std::string & text, int x, int y, int c0, int c1, int c2)
+  {
+    constexpr int S = 3;
+    for (size_t k = 0; k < text.size(); k++) {
+      const uint8_t * g = glyph(text[k]);
+      if (!g) continue;
+      for (int r = 0; r < 7; r++)
+        for (int c = 0; c < 5; c++) {
+          if (!((g[r] >> (4 - c)) & 1)) continue;
+          for (int dy = 0; dy < S; dy++)
+            for (int dx = 0; dx < S; dx++) {
+              const int px = x + int(k) * 6 * S + c * S + dx, py = y - 7 * S + r * S + dy;
+              if (px < 0 || py < 0 || px >= img.cols || py >= img.rows) continue;
+              uint8_t * p = img.data + (size_t(py) * img.cols + px) * 3;
+              p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2);
+            }
+        }
     }
   }
 

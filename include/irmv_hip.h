@@ -30,7 +30,6 @@ extern "C" {
 #define IRMV_ERR_ARG (-1)      /* bad argument / configuration            */
 #define IRMV_ERR_HIP (-2)      /* HIP runtime failure (message has detail) */
 #define IRMV_ERR_MODEL (-3)    /* weight blob missing or not matching      */
-#define IRMV_ERR_OVERFLOW (-4) /* reserved, never returned (the candidate list holds every (anchor, class) pair) */
 
 #define IRMV_RESIZE_STRETCH 0   /* reference behaviour: src/yolo_engine.cpp:186-190 */
 #define IRMV_RESIZE_LETTERBOX 1 /* north-star variant */
@@ -150,6 +149,17 @@ void irmv_engine_destroy(irmv_engine *e);
 int irmv_engine_num_slots(const irmv_engine *e);
 int irmv_engine_max_det(const irmv_engine *e);
 int irmv_engine_num_streams(const irmv_engine *e);
+
+/* ---- NUMA placement of the frame hand-off (multi-GPU nodes; the reference is single-device, test/yolo_test.cpp:16) ----
+ * An engine allocates and first-touches its pinned frame slots on the host NUMA node closest to its device
+ * (hipDeviceAttributeHostNumaId; IRMV_NUMA=0 switches that off).  The threads that FILL the slots and submit belong on the
+ * same node: a runner binds each of them with irmv_numa_bind_thread(node of its device) before it creates the engine. */
+int irmv_engine_numa_node(const irmv_engine *e);     /* host NUMA node of the engine's device; -1 unknown */
+int irmv_engine_numa_placed(const irmv_engine *e);   /* 1: the frame slots were allocated under that node's CPU set and memory policy */
+int irmv_numa_device_node(int device, int *node);    /* the same attribute without an engine (before irmv_engine_create) */
+int irmv_numa_bind_thread(int node);                 /* sched_setaffinity(calling thread, CPUs of /sys/devices/system/node/nodeN/cpulist within the process's cpuset) */
+int irmv_numa_page_node(const void *p);              /* node holding the page of p (move_pages query); < 0 unknown */
+int irmv_numa_parse_cpulist(const char *s, int *cpus, int cap);   /* "0-3,8" -> {0,1,2,3,8}; returns the count (test aid) */
 
 /* Pinned host frame slot (src_height*src_width*3 bytes, HWC u8), valid for the
  * engine's lifetime; producer threads write straight into it -- the counterpart

@@ -33,6 +33,24 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-
           "-mllvm", "-amdgpu-mfma-vgpr-form", "-I", INCLUDE]
 
 
+def source_hash() -> str:
+    """sha256 over everything that determines the kernels of libirmv_hip.so: the sources and headers of csrc/, the C ABI
+    header and the compiler flags.  The counter files under profiles/ carry it (scripts/build_stamp.py) and bench.py drops
+    their numbers when it differs from the tree it runs in -- a hash of the BINARY would not survive a rebuild elsewhere."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(set([s for s, _ in SOURCES] + ["irmv_common.hpp", "pnp_device.hpp", "numa.hpp"]))
+    for n in names:
+        pth = os.path.join(CSRC, n)
+        if os.path.exists(pth):
+            h.update(n.encode() + b"\0" + open(pth, "rb").read())
+    h.update(open(os.path.join(INCLUDE, "irmv_hip.h"), "rb").read())
+    h.update(" ".join(COMMON[:-2]).encode())          # flags without the machine-specific include path
+    for src, extra in SOURCES:
+        h.update((src + " " + " ".join(extra)).encode())
+    return h.hexdigest()
+
+
 def hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -68,7 +86,7 @@ def build_comm(force: bool = False, verbose: bool = False) -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "irmv_common.hpp"), os.path.join(CSRC, "pnp_device.hpp"), os.path.join(INCLUDE, "irmv_hip.h"), __file__]
+    headers = [os.path.join(CSRC, "irmv_common.hpp"), os.path.join(CSRC, "pnp_device.hpp"), os.path.join(CSRC, "numa.hpp"), os.path.join(INCLUDE, "irmv_hip.h"), __file__]
     objs = []
     cc = hipcc()
     for src, extra in SOURCES:

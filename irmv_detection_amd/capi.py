@@ -10,7 +10,7 @@ import os
 
 from . import _build
 
-OK, ERR_ARG, ERR_HIP, ERR_MODEL, ERR_OVERFLOW = 0, -1, -2, -3, -4
+OK, ERR_ARG, ERR_HIP, ERR_MODEL = 0, -1, -2, -3
 RESIZE_STRETCH, RESIZE_LETTERBOX = 0, 1
 ARMOR_SMALL, ARMOR_LARGE = 0, 1
 SUBMIT_H2D = 1
@@ -81,6 +81,12 @@ SYMBOLS = [
     ("irmv_engine_num_slots", C.c_int, [_P]),
     ("irmv_engine_max_det", C.c_int, [_P]),
     ("irmv_engine_num_streams", C.c_int, [_P]),
+    ("irmv_engine_numa_node", C.c_int, [_P]),
+    ("irmv_engine_numa_placed", C.c_int, [_P]),
+    ("irmv_numa_device_node", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    ("irmv_numa_bind_thread", C.c_int, [C.c_int]),
+    ("irmv_numa_page_node", C.c_int, [C.c_void_p]),
+    ("irmv_numa_parse_cpulist", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.c_int]),
     ("irmv_engine_src_buffer", C.POINTER(C.c_uint8), [_P, C.c_int]),
     ("irmv_engine_src_device_buffer", C.c_void_p, [_P, C.c_int]),
     ("irmv_engine_submit", C.c_int, [_P, C.c_int, C.c_int, C.c_uint32]),
@@ -142,12 +148,6 @@ def check(rc: int, allow=()):
 
 
 def device_count() -> int:
-    n = C.c_int(0)
-    check(load().irmv_device_count(C.byref(n)))
-    return n.value
-
-
-def device_count() -> int:
     """HIP devices visible to this process (0 without a GPU)."""
     n = C.c_int(0)
     return n.value if load().irmv_device_count(C.byref(n)) == OK else 0
@@ -155,3 +155,19 @@ def device_count() -> int:
 
 def device_synchronize(device: int = 0) -> None:
     check(load().irmv_device_synchronize(device))
+
+
+def numa_parse_cpulist(text: str):
+    """The library's own parser of a sysfs cpulist ("0-3,8,10-11"), as used for thread placement."""
+    buf = (C.c_int * 4096)()
+    n = load().irmv_numa_parse_cpulist(text.encode(), buf, 4096)
+    return [buf[i] for i in range(min(n, 4096))]
+
+
+def numa_bind_to_device(device: int = 0) -> int:
+    """Bind the calling thread to the CPUs of the host NUMA node closest to `device` (multi-GPU runners call this per rank /
+    per worker thread BEFORE creating the engine and filling its slots).  Returns the node, or -1 if nothing was bound."""
+    node = C.c_int(-1)
+    if load().irmv_numa_device_node(device, C.byref(node)) != OK or node.value < 0:
+        return -1
+    return node.value if load().irmv_numa_bind_thread(node.value) == OK else -1

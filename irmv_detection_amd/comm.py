@@ -71,27 +71,38 @@ def id_file() -> str:
     return os.path.join(tempfile.gettempdir(), f"irmv_comm_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.id")
 
 
-def exchange_id(rank: int, make_id, path: Optional[str] = None, timeout_s: float = 180.0) -> bytes:
-    """Rank 0 calls make_id() and publishes the bytes (write + atomic rename); the others wait for the file."""
+_T_START = time.time()      # this process's start (import) time: id files much older than it belong to an earlier launch
+NONCE_BYTES = 16
+STALE_S = 120.0
+
+
+def exchange_id(rank: int, make_id, path: Optional[str] = None, timeout_s: float = 180.0, with_nonce: bool = False):
+    """Rank 0 calls make_id() and publishes the bytes (write + atomic rename) followed by a per-launch nonce; the others
+    wait for the file.  A file left behind by an earlier launch that happened to share the launcher pid and port is never
+    accepted: rank 0 replaces it, and the others ignore a file written more than STALE_S before they started.
+    -> the id bytes, or (id bytes, nonce string) with with_nonce."""
     path = path or id_file()
     if rank == 0:
         data = make_id()
+        nonce = f"{int(_T_START * 1e3) & 0xffffffffff:010x}{os.getpid() & 0xffffff:06x}".encode()
+        assert len(nonce) == NONCE_BYTES
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as f:
-            f.write(data)
+            f.write(data + nonce)
         os.replace(tmp, path)
-        return data
+        return (data, nonce.decode()) if with_nonce else data
     t0 = time.time()
     while True:
         try:
-            with open(path, "rb") as f:
-                data = f.read()
-            if len(data) == ID_BYTES:
-                return data
-        except FileNotFoundError:
+            if os.path.getmtime(path) >= _T_START - STALE_S:
+                with open(path, "rb") as f:
+                    data = f.read()
+                if len(data) == ID_BYTES + NONCE_BYTES:
+                    return (data[:ID_BYTES], data[ID_BYTES:].decode()) if with_nonce else data[:ID_BYTES]
+        except (FileNotFoundError, OSError):
             pass
         if time.time() - t0 > timeout_s:
-            raise CommError(f"rank {rank}: no communicator id at {path} after {timeout_s:.0f} s")
+            raise CommError(f"rank {rank}: no (fresh) communicator id at {path} after {timeout_s:.0f} s")
         time.sleep(0.02)
 
 
@@ -102,6 +113,7 @@ class FileReduce:
     then replaced by every rank generating the same seeded blob)."""
 
     def __init__(self, rank: int, world: int, base: str):
+        # `base` carries the launch's nonce (Comm.__init__): rounds of another launch can never be read as this one's
         self.rank, self.world, self.base, self.seq = rank, world, base, 0
 
     def gather(self, x: float, timeout_s: float = 600.0) -> List[float]:
@@ -130,13 +142,25 @@ class FileReduce:
         return vals
 
     def close(self) -> None:
-        """A last round as the closing handshake: once it is complete every rank has read everything before it, so those
-        files go; the closing round's own file (a few bytes per rank) stays -- a peer may not have read it yet."""
+        """Two closing rounds: once the second is complete on a rank, every rank has READ the first, so each rank removes
+        its own files of every round up to the first; rank 0 then gives the peers a moment to read the second round's files
+        and removes whatever of this launch is left (its prefix is unique to the launch)."""
+        import glob
         self.gather(0.0)
-        for q in (self.seq - 2, self.seq - 1):
+        self.gather(0.0)
+        for q in range(1, self.seq):
             path = f"{self.base}.r{q}.{self.rank}"
-            if q > 0 and os.path.exists(path):
+            if os.path.exists(path):
                 os.remove(path)
+        if self.rank == 0:
+            time.sleep(0.3)
+        else:
+            return
+        for path in glob.glob(glob.escape(self.base) + ".r*"):
+            try:
+                os.remove(path)
+            except OSError:
+                pass
 
 
 class Comm:
@@ -154,24 +178,43 @@ class Comm:
         self.native_error = None
         if self.world > 1:
             self._id_path = id_file()
-            self._files = FileReduce(self.rank, self.world, self._id_path)
-            ok = 1.0
+            if self.rank == 0 and os.path.exists(self._id_path):
+                os.remove(self._id_path)            # a leftover of an earlier launch with this launcher pid and port
+            # Stage 1, BEFORE anyone enters ncclCommInitRank (which blocks until every rank has joined): each rank reports
+            # whether its library loaded, its device exists and the id is a real one.  One failing rank then takes everybody
+            # to the fallback together, instead of leaving the healthy ranks inside RCCL waiting for it.
+            L, uid, pre_ok = None, bytes(ID_BYTES), 1.0
             try:
                 L = load()
+            except (CommError, OSError) as e:
+                pre_ok, self.native_error = 0.0, f"libirmv_comm.so: {e}"
 
-                def make():
-                    buf = C.create_string_buffer(ID_BYTES)
-                    _check(L.irmv_comm_unique_id(buf))
-                    return buf.raw
-                uid = exchange_id(self.rank, make, self._id_path)
-                if uid == bytes(ID_BYTES):
-                    raise CommError("rank 0 could not create a communicator id")
-                _check(L.irmv_comm_init_rank(uid, self.world, self.rank, self.device, C.byref(self._h)))
-            except (CommError, OSError) as e:       # RCCL refused (or the library is missing): say so, then agree with the others
-                ok, self.native_error = 0.0, str(e)
-                if self.rank == 0 and not os.path.exists(self._id_path):   # the others are waiting for an id: give them a dummy
-                    exchange_id(0, lambda: bytes(ID_BYTES), self._id_path)
-            self.native = min(self._files.gather(ok)) > 0.5
+            def make():
+                if L is None:
+                    return bytes(ID_BYTES)          # the others are waiting for a file: a dummy id, refused below
+                buf = C.create_string_buffer(ID_BYTES)
+                if L.irmv_comm_unique_id(buf) != 0:
+                    return bytes(ID_BYTES)
+                return buf.raw
+            uid, nonce = exchange_id(self.rank, make, self._id_path, with_nonce=True)
+            self._files = FileReduce(self.rank, self.world, f"{self._id_path}.{nonce}")
+            if uid == bytes(ID_BYTES):
+                pre_ok, self.native_error = 0.0, self.native_error or "rank 0 could not create a communicator id"
+            try:
+                from . import capi
+                if self.device < 0 or self.device >= capi.device_count():
+                    pre_ok, self.native_error = 0.0, self.native_error or f"no HIP device {self.device} on this rank"
+            except Exception as e:                  # noqa: BLE001 -- whatever keeps this rank from counting devices keeps it out of RCCL
+                pre_ok, self.native_error = 0.0, self.native_error or f"device count: {e}"
+            ok = 1.0 if min(self._files.gather(pre_ok)) > 0.5 else 0.0
+            if ok > 0.5:
+                # Stage 2: everybody goes in.  A rank that fails in here reports it and then waits only briefly: its peers
+                # may be blocked inside ncclCommInitRank for good, and a prompt non-zero exit lets the launcher end the job.
+                try:
+                    _check(L.irmv_comm_init_rank(uid, self.world, self.rank, self.device, C.byref(self._h)))
+                except (CommError, OSError) as e:
+                    ok, self.native_error = 0.0, str(e)
+            self.native = min(self._files.gather(ok, timeout_s=600.0 if ok > 0.5 else 60.0)) > 0.5
             if not self.native:
                 import sys
                 print(f"[irmv_comm] rank {self.rank}: RCCL communicator not available on every rank"

@@ -33,6 +33,7 @@
 
 #include "../../include/irmv_hip.h"
 #include "irmv_common.hpp"
+#include "numa.hpp"
 
 using namespace irmv;
 
@@ -202,6 +203,8 @@ struct irmv_engine {
     int nc = 0, nk = 0, A = 0, no = 0;
     int backbone = 0;   // 0: C2f stages (YOLOv8n), 1: ShuffleNetV2 stages (blob header)
     int num_cus = 256;  // compute units of the device (persistent kernels size their grids by it)
+    int numa_node = -1;     // host NUMA node closest to the device (hipDeviceAttributeHostNumaId); -1: unknown
+    bool numa_placed = false;   // the pinned frame slots were allocated and first touched under that node's CPU set and memory policy
     // Single-frame engines: the independent Detect-branch convs of the three levels as one launch per stage (k_conv.hip
     // conv3x3_lds_multi / conv_mfma_multi).  family 0: LDS 3x3 with tile (mt 1, nt); 1: direct kernel with cfg.
     struct HeadGroup { std::vector<int> members; int family = 0, nt = 1; ConvCfg cfg{}; char name[48] = {0}; };
@@ -691,9 +694,20 @@ static int build_engine(irmv_engine *e)
     { const char *ic = getenv("IRMV_INLINE_COPIES"); e->inline_copies = ic && ic[0] == '1'; }
     e->slot_owner.assign(S, nullptr);
     e->frame_bytes = (size_t)c.src_width * c.src_height * 3;
-    HIP_TRY(hipHostMalloc((void **)&e->src_host, e->frame_bytes * S, hipHostMallocDefault));
-    log_range(e, "pinned src_host", e->src_host, e->frame_bytes * S);
-    memset(e->src_host, 0, e->frame_bytes * S);
+    {
+        // NUMA-local frame slots (SURVEY section 7 "hard parts": on a full node the copy engines read 8 x 14 k FPS x 3.93 MB =
+        // 440 GB/s of host memory): the creating thread runs on the CPUs of the GPU's own socket and prefers its memory while
+        // the slots are allocated and first touched (hipHostMallocNumaUser = "follow the caller's policy"); affinity and
+        // policy are restored afterwards.  IRMV_NUMA=0: plain hipHostMallocDefault wherever the thread happens to run.
+        const char *nv = getenv("IRMV_NUMA");
+        const bool want = e->numa_node >= 0 && !(nv && nv[0] == '0');
+        numa::ScopedNode scope(want ? e->numa_node : -1);
+        const bool user = want && scope.policy();
+        HIP_TRY(hipHostMalloc((void **)&e->src_host, e->frame_bytes * S, user ? (hipHostMallocDefault | hipHostMallocNumaUser) : hipHostMallocDefault));
+        log_range(e, "pinned src_host", e->src_host, e->frame_bytes * S);
+        memset(e->src_host, 0, e->frame_bytes * S);   // first touch, by the bound thread
+        e->numa_placed = user && scope.bound();
+    }
     TRY(dev_alloc(e, (void **)&e->src_dev, e->frame_bytes * S));
     HIP_TRY(hipMemset(e->src_dev, 0, e->frame_bytes * S));
     TRY(dev_alloc(e, (void **)&e->rot_dev, e->frame_bytes));
@@ -1171,6 +1185,9 @@ extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) e->num_cus = cus;
+        int node = -1;
+        if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, cfg->device) == hipSuccess) e->numa_node = node;
+        else (void)hipGetLastError();   // an older runtime serving the library (torch's bundled ROCm 7.0) does not know the attribute: no node, and no sticky error for the checks behind the tuning launches
     }
     int rc = load_blob(e.get());
     e->cfg.weights_path = nullptr;  // caller-owned, not retained
@@ -1192,6 +1209,29 @@ extern "C" int irmv_engine_num_slots(const irmv_engine *e) { return e ? e->cfg.n
 extern "C" int irmv_engine_max_det(const irmv_engine *e) { return e ? e->cfg.max_det : 0; }
 extern "C" int irmv_engine_num_streams(const irmv_engine *e) { return e ? e->num_streams : 0; }
 extern "C" int irmv_engine_num_anchors(const irmv_engine *e) { return e ? e->A : 0; }
+extern "C" int irmv_engine_numa_node(const irmv_engine *e) { return e ? e->numa_node : -1; }
+extern "C" int irmv_engine_numa_placed(const irmv_engine *e) { return e && e->numa_placed ? 1 : 0; }
+
+// ---- NUMA helpers for the threads / ranks that feed an engine (tools/irmv_multi_gpu.cpp, bench.py ranks) ----
+extern "C" int irmv_numa_device_node(int device, int *node)
+{
+    if (!node) return fail(IRMV_ERR_ARG, "node is null");
+    int v = -1;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeHostNumaId, device) != hipSuccess) {
+        (void)hipGetLastError();        // (attribute unknown to the runtime that serves the library: not an error of the caller's)
+        v = -1;
+    }
+    *node = v;
+    return IRMV_OK;
+}
+extern "C" int irmv_numa_bind_thread(int node) { return numa::bind_thread_to_node(node) ? IRMV_OK : fail(IRMV_ERR_ARG, "no usable CPU on that NUMA node (or none listed in sysfs)"); }
+extern "C" int irmv_numa_page_node(const void *p) { return numa::page_node(p); }
+extern "C" int irmv_numa_parse_cpulist(const char *s, int *cpus, int cap)
+{
+    const std::vector<int> v = numa::parse_cpulist(s);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) if (cpus) cpus[i] = v[i];
+    return (int)v.size();
+}
 extern "C" int irmv_engine_head_channels(const irmv_engine *e) { return e ? e->no : 0; }
 
 extern "C" uint8_t *irmv_engine_src_buffer(irmv_engine *e, int slot)
@@ -1275,15 +1315,14 @@ static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int co
 static int autotune_convs(irmv_engine *e)
 {
     const char *env = getenv("IRMV_AUTOTUNE");
-    if (env && env[0] == '0') return IRMV_OK;
+    const bool no_tuning = env && env[0] == '0';   // no timing launches: every layer takes the first legal tile of ITS family (same K order as a tuned engine: bit-identical)
     tune_cache_load();
     hipEvent_t ea, eb;
     HIP_TRY(hipEventCreate(&ea));
     HIP_TRY(hipEventCreate(&eb));
     const int counts[2] = {stream_share(e, e->cfg.num_slots), 1};   // the batch one graph actually runs; single frame
     const bool verbose = getenv("IRMV_AUTOTUNE_VERBOSE") != nullptr;
-    const char *fam_env = getenv("IRMV_CONV_FAMILY");
-    const bool only_direct = fam_env && !strcmp(fam_env, "direct");
+    const bool only_direct = false;   // (IRMV_CONV_FAMILY=direct, which changed the K order of the 3x3 layers, was removed in round 4)
     for (Op &op : e->ops) {
         if (op.kind != OP_CONV) continue;
         for (int pass = 0; pass < (counts[0] > 1 ? 2 : 1); pass++) {
@@ -1311,6 +1350,9 @@ static int autotune_convs(irmv_engine *e)
                         const int li = nt == 4 ? 2 : (nt == 2 ? 1 : 0);
                         lds_ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, mt, nt, &pr) > 0;
                     }
+            // IRMV_FORCE_S2=lds|ct|deep (parity test): the stride-2 layers of the LDS family on ONE of their three bit-identical
+            // implementations -- the LDS kernel, the direct kernel walking K chunk-major, its deep-prefetch form
+            const char *force_s2 = getenv("IRMV_FORCE_S2");
             char key[160];
             snprintf(key, sizeof key, "gfx950|%d.%d.%d.%d.%d.%d|%dx%d>%dx%d|c%d.%d.%d.%d>%d|ld%d.%d.%d|n%d|%d", op.cfg.ks, op.cfg.stride,
                      (int)op.cfg.cin16, op.cfg.act, (int)op.cfg.out_f32, (int)lds_ok, a.Hin, a.Win, a.Hout, a.Wout, a.s0.C, a.s1.C, a.s0.shift,
@@ -1322,7 +1364,7 @@ static int autotune_convs(irmv_engine *e)
             {
                 std::lock_guard<std::mutex> lk(g_tune_mu);
                 auto hit = g_tune_cache.find(key);
-                if (hit != g_tune_cache.end() && !verbose) {
+                if (hit != g_tune_cache.end() && !verbose && !no_tuning && !(force_s2 && lds_ok && op.cfg.stride == 2)) {
                     const ConvCfg &h = hit->second;
                     const bool pow2 = (h.mt == 1 || h.mt == 2 || h.mt == 4) && (h.nt == 1 || h.nt == 2 || h.nt == 4) && (h.ipw == 1 || h.ipw == 2 || h.ipw == 4 || (h.wr && h.ipw >= 1));
                     // family: LDS-staged, or (single-frame steps only) its chunk-major stand-in on the direct kernel; never both flags
@@ -1359,9 +1401,8 @@ static int autotune_convs(irmv_engine *e)
             }
             if (!have_hit)
             {
-                // diagnostic: IRMV_FORCE_S2=lds|ct|deep restricts the stride-2 layers of the LDS family to one implementation
-                static const char *force_s2 = getenv("IRMV_FORCE_S2");
                 auto time_cfg = [&](const ConvCfg &c) -> int {
+                    if (no_tuning && best < 1e29f) return IRMV_OK;   // IRMV_AUTOTUNE=0: the first candidate that runs is the choice
                     if (force_s2 && lds_ok && op.cfg.stride == 2) {
                         const char *kind = c.lds ? "lds" : (c.deep ? "deep" : "ct");
                         if (strcmp(kind, force_s2) != 0) return IRMV_OK;
@@ -1369,6 +1410,7 @@ static int autotune_convs(irmv_engine *e)
                     bool ok = true;
                     for (int i = 0; i < 2 && ok; i++) ok = run_conv(op, c, a, counts[pass], e->stream);
                     if (!ok) return IRMV_OK;
+                    if (no_tuning) { best = 0.f; best_cfg = c; return IRMV_OK; }
                     float ms = 1e30f;   // best of 3 bursts of 4
                     for (int rep = 0; rep < 3; rep++) {
                         HIP_TRY(hipEventRecord(ea, e->stream));
@@ -1492,7 +1534,7 @@ static int autotune_convs(irmv_engine *e)
                     }
                 }
             }
-            { std::lock_guard<std::mutex> lk(g_tune_mu); g_tune_cache[key] = best_cfg; }
+            if (!no_tuning && !(force_s2 && lds_ok && op.cfg.stride == 2)) { std::lock_guard<std::mutex> lk(g_tune_mu); g_tune_cache[key] = best_cfg; }   // (forced / untuned choices are not what a later engine should replay)
             if (pass == 0) { op.cfg = best_cfg; cfg_name(op.cfg, op.kname, sizeof op.kname); }
             else { op.cfg_one = best_cfg; cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
             if (counts[0] == 1) { op.cfg_one = op.cfg; cfg_name(op.cfg_one, op.kname_one, sizeof op.kname_one); }
@@ -1624,7 +1666,7 @@ static int build_head_groups(irmv_engine *e)
         if (best_ms < 0.f) return;
         const float sep = members_time(mem);
         if (getenv("IRMV_AUTOTUNE_VERBOSE") || getenv("IRMV_GROUP_VERBOSE")) fprintf(stderr, "[irmv group] %s: %zu convs, one launch %.2f us, separate %.2f us\n", label, mem.size(), best_ms * 1e3f, sep * 1e3f);
-        if (sep > 0.f && best_ms >= sep && !getenv("IRMV_GROUP_FORCE")) return;
+        if (sep > 0.f && best_ms >= sep && !getenv("IRMV_GROUP_FORCE")) return;   // IRMV_GROUP_FORCE=1 (parity test): group even where the one launch timed slower
         if (family == 0) snprintf(best.name, sizeof best.name, "%s_lds_mt1_nt%d_x%zu", label, best.nt, mem.size());
         else snprintf(best.name, sizeof best.name, "%s_direct_x%zu", label, mem.size());
         const int gi = (int)e->head_groups.size();
@@ -1642,11 +1684,7 @@ static int build_head_groups(irmv_engine *e)
         g2_fused = g2_fused && c2 >= 0 && c3 >= 0 && e->ops[c2].fuse_next >= 0 && e->ops[c3].fuse_next >= 0;
         if (kpt) { g3.push_back(find_op("model.22.cv4." + si + ".1")); g4.push_back(find_op("model.22.cv4." + si + ".2")); }
     }
-    {
-        const char *fnt = getenv("IRMV_GROUP_S0_NT");   // diagnostic: pin the first-stage group's channel tiling
-        if (fnt) try_group(g1, 0, {atoi(fnt)}, "head_s0");
-        else try_group(g1, 0, {1, 2}, "head_s0");
-    }
+    try_group(g1, 0, {1, 2}, "head_s0");
     if (g2_fused) try_group(g2, 0, {4}, "head_s1+1x1");
     // A group is launched where its FIRST member stands in the op list, so every member's input must exist by then.  The
     // first-stage convs precede all of these; the keypoint finals (cv4.i.2) read cv4.i.1, and cv4.1.1 / cv4.2.1 stand BEHIND

@@ -389,7 +389,8 @@ constexpr int pix_stride(int stride) { return stride == 2 ? 80 : 96; }
 
 // hipFuncSetAttribute is per device: remember, per kernel, on which devices it has been applied.  Engines may be created
 // and run from several threads (one per GPU): the check, the attribute call and the flag update are one critical section,
-// so no thread launches before the limit is raised.
+// so no thread launches before the limit is raised.  (The mutex is taken on every launch CALL -- engine creation, tuning,
+// graph capture, eager profiling; a captured step is replayed without any of this code.)
 static std::mutex g_attr_mu;
 template <class F>
 static void once_per_device(unsigned long long &mask, F set_attribute)
@@ -698,13 +699,21 @@ bool launch_conv_pw(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
 #define IRMV_PWN(KS_, NBW_)                                                                                          \
         if (a.ksteps == KS_ && nbw == NBW_) {                                                                          \
             static unsigned long long attr_done = 0;                                                                   \
-            static int per_cu = 1;   /* workgroups a CU holds (registers and LDS): sizes the grid to one round */       \
-            once_per_device(attr_done, [lds] {                                                                         \
+            /* per DEVICE (engines on several GPUs are created from concurrent threads): workgroups a CU holds (registers   \
+               and LDS) and the device's CU count size the grid to one round.  Element `dev` is written once, inside the    \
+               critical section of once_per_device, before any launch on that device leaves it. */                        \
+            static int per_cu[64], cus[64];                                                                            \
+            int dev = 0;                                                                                               \
+            (void)hipGetDevice(&dev);                                                                                  \
+            dev &= 63;                                                                                                 \
+            once_per_device(attr_done, [lds, dev] {                                                                    \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_pwn_kernel<KS_, NBW_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                int nb = 0;                                                                                            \
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(conv1x1_pwn_kernel<KS_, NBW_>), 512, lds) == hipSuccess && nb >= 1) per_cu = nb > 2 ? 2 : nb; \
+                int nb = 0, nc = 0;                                                                                    \
+                per_cu[dev] = 1; cus[dev] = 256;                                                                       \
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(conv1x1_pwn_kernel<KS_, NBW_>), 512, lds) == hipSuccess && nb >= 1) per_cu[dev] = nb > 2 ? 2 : nb; \
+                if (hipDeviceGetAttribute(&nc, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && nc > 0) cus[dev] = nc; \
             });                                                                                                        \
-            int wg = (256 * per_cu + groups - 1) / groups;               /* the chip in one round ... */               \
+            int wg = (cus[dev] * per_cu[dev] + groups - 1) / groups;     /* the chip in one round ... */               \
             if (wg > (units + 7) / 8) wg = (units + 7) / 8;              /* ... but a 16-pixel unit per wave at least (20 x 20 maps: more  \
                                                                             workgroups beat longer pipelines: 2 / 3 units per wave +7 / +25 %) */ \
             if (wg < 1) wg = 1;                                                                                        \
@@ -740,7 +749,9 @@ constexpr int lds_pmax(int stride, int mt, bool tile2d, int wr = 0) { return wr 
 
 #ifndef IRMV_ABL
 #define IRMV_ABL 0   // timing ablations of conv3x3_lds_kernel (scripts/probes/conv_probe.cpp); results are wrong with any bit set:
-#endif               // 1 weights staged once, 2 patch staged once, 4 no MFMAs, 8 no SiLU, 16 no output stores
+#endif               // 1 weights staged once, 2 patch staged once, 4 no MFMAs, 8 no SiLU, 16 no output stores,
+                     // 32 the k-step's MFMAs as half as many v_mfma_f32_32x32x16_f16 on the same fragment registers (same matrix-pipe
+                     //    time, half the issue slots: what that shape would buy before anything is built for it)
 #ifndef IRMV_EXP
 #define IRMV_EXP 0   // structural experiments of the same probe: 1 late epilogue, 2 staggered second workgroup per CU
 #endif
@@ -1133,6 +1144,15 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         constexpr int KS = (WR > 0 ? WR : 1) * 9;
         auto &accx = acc[0];
         half8 A[2][NT], B[2][MT];
+#if IRMV_ABL & 32
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        constexpr int NC32 = MT * NT >= 4 ? MT * NT / 4 : 1;
+        f32x16 c32[NC32];   // the wave's MT x NT x 4 accumulator registers as 32 x 32 tiles
+#pragma unroll
+        for (int t = 0; t < MT * NT / 4; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) c32[t][i] = accx[(t * 4 + i / 4) / NT][(t * 4 + i / 4) % NT][i % 4];
+#endif
         auto frag = [&](auto ks_, half8 (&Af)[NT], half8 (&Bf)[MT]) {
             constexpr int ks = decltype(ks_)::value, c = ks / 9, tap = ks % 9, kh = tap / 3, kw = tap % 3;
             const unsigned char *s_pl = s_patch + (size_t)c * a_patch_bytes + (kh * PW + kw) * pix_stride(STRIDE);
@@ -1147,11 +1167,19 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
             constexpr int ks = decltype(ks_)::value;
             if constexpr (ks + 1 < KS) frag(std::integral_constant<int, ks + 1>{}, A[(ks + 1) & 1], B[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+#if IRMV_ABL & 32
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt += 2)   // (timing only: these fragments are not laid out for this shape)
+                    c32[(mt * NT + nt) / 4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks & 1][nt], B[ks & 1][mt], c32[(mt * NT + nt) / 4], 0, 0, 0);
+#else
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
                     if (!(IRMV_ABL & 4)) accx[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks & 1][nt], B[ks & 1][mt], accx[mt][nt], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         auto run = [&](auto self, auto ks_) -> void {
@@ -1164,6 +1192,12 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         run(run, std::integral_constant<int, 0>{});
 #if IRMV_EXP & 16
         __builtin_amdgcn_s_setprio(0);
+#endif
+#if IRMV_ABL & 32
+#pragma unroll
+        for (int t = 0; t < MT * NT / 4; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) accx[(t * 4 + i / 4) / NT][(t * 4 + i / 4) % NT][i % 4] = c32[t][i];
 #endif
     };
     auto mma_step = [&]() {

@@ -139,6 +139,8 @@ class YoloEngine:
         self.max_det = max_det
         self.enable_profiling = enable_profiling
         self.num_streams = L.irmv_engine_num_streams(self._h)
+        self.numa_node = L.irmv_engine_numa_node(self._h)            # host NUMA node closest to the device (-1 unknown)
+        self.numa_placed = bool(L.irmv_engine_numa_placed(self._h))  # the pinned frame slots were allocated / first touched there
         self.num_anchors = L.irmv_engine_num_anchors(self._h)
         self.head_channels = L.irmv_engine_head_channels(self._h)
         self._dets = (capi.Det * max_det)()
@@ -170,6 +172,11 @@ class YoloEngine:
             raise IrmvError(capi.ERR_ARG, "bad slot")
         w, h = self.src_image_size
         return np.ctypeslib.as_array(p, shape=(h, w, 3))
+
+    def src_page_node(self, slot: int = 0) -> int:
+        """NUMA node that holds the first page of the pinned frame slot (move_pages query); < 0: unknown."""
+        p = self._L.irmv_engine_src_buffer(self._h, slot)
+        return int(self._L.irmv_numa_page_node(C.cast(p, C.c_void_p)))
 
     def detect(self, slot: Optional[int] = None) -> List[bbox]:
         """std::vector<bbox> detect() (src/yolo_engine.cpp:153-177)."""
@@ -209,10 +216,34 @@ class YoloEngine:
             res.append(a)
         return res
 
+    # 5 x 7 bitmap glyphs of the ArmorClass names (B1..B5, BO, BS, R1..R5, RO, RS, UNKNOWN): the same table as the C++ facade
+    # (include/irmv_detection/yolo_engine.hpp), drawn at scale 3 = the size of FONT_HERSHEY_SIMPLEX at scale 1
+    _GLYPHS = {"B": (0x1e, 0x11, 0x11, 0x1e, 0x11, 0x11, 0x1e), "R": (0x1e, 0x11, 0x11, 0x1e, 0x14, 0x12, 0x11),
+               "O": (0x0e, 0x11, 0x11, 0x11, 0x11, 0x11, 0x0e), "S": (0x0f, 0x10, 0x10, 0x0e, 0x01, 0x01, 0x1e),
+               "U": (0x11, 0x11, 0x11, 0x11, 0x11, 0x11, 0x0e), "N": (0x11, 0x19, 0x15, 0x13, 0x11, 0x11, 0x11),
+               "K": (0x11, 0x12, 0x14, 0x18, 0x14, 0x12, 0x11), "W": (0x11, 0x11, 0x11, 0x15, 0x15, 0x1b, 0x11),
+               "1": (0x04, 0x0c, 0x04, 0x04, 0x04, 0x04, 0x0e), "2": (0x0e, 0x11, 0x01, 0x02, 0x04, 0x08, 0x1f),
+               "3": (0x1e, 0x01, 0x01, 0x0e, 0x01, 0x01, 0x1e), "4": (0x02, 0x06, 0x0a, 0x12, 0x1f, 0x02, 0x02),
+               "5": (0x1f, 0x10, 0x1e, 0x01, 0x01, 0x11, 0x0e)}
+
+    @classmethod
+    def _draw_label(cls, image: np.ndarray, text: str, x: int, y: int, color) -> None:
+        """cv::putText(image, text, (x, y), FONT_HERSHEY_SIMPLEX, 1, color, 2) without OpenCV: (x, y) is the text's bottom-left corner."""
+        S = 3
+        h, w = image.shape[:2]
+        for k, ch in enumerate(text):
+            g = cls._GLYPHS.get(ch)
+            if g is None:
+                continue
+            for r in range(7):
+                for c in range(5):
+                    if (g[r] >> (4 - c)) & 1:
+                        x0, y0 = x + k * 6 * S + c * S, y - 7 * S + r * S
+                        image[max(y0, 0):max(min(y0 + S, h), 0), max(x0, 0):max(min(x0 + S, w), 0)] = color
+
     def visualize_bboxes(self, image: np.ndarray, bboxes: Sequence[bbox]) -> None:
-        """Draw 2-px rectangles in place; like the reference, print and return on
-        a size mismatch (src/yolo_engine.cpp:222-243).  Class-name text is left to
-        the caller's drawing library."""
+        """Draw 2-px rectangles and the class name in place; like the reference, print and return on
+        a size mismatch (src/yolo_engine.cpp:222-243)."""
         w, h = self.src_image_size
         if image.shape[1] != w or image.shape[0] != h:
             print("[YoloEngine::visualize_bboxes] Image size mismatch")
@@ -229,6 +260,7 @@ class YoloEngine:
                 for x in (x1 + t, x2 - t):
                     if 0 <= x < w:
                         image[y1c:y2c + 1, x] = color
+            self._draw_label(image, b.class_id.name, x1, y1, color)
 
     # ---- batched / asynchronous extension (MI355X-first surface) ------------------
     def submit(self, first_slot: int = 0, count: Optional[int] = None, h2d: bool = True, async_upload: bool = False) -> None:

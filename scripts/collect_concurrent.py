@@ -21,6 +21,7 @@ for r in csv.DictReader(open(sys.argv[1])):
 tot = sum(a["total_ns"] for a in acc.values()) or 1.0
 out = {k: dict(calls=a["calls"], avg_launch_ms=round(a["total_ns"] / a["calls"] * 1e-6, 6), share_of_kernel_time=round(a["total_ns"] / tot, 4),
                symbols=sorted(a["symbols"])) for k, a in acc.items()}
-json.dump(dict(source="rocprofv3 --kernel-trace --stats -- python3 bench.py (benchmarked concurrent replay)", kernels=out), open(sys.argv[2], "w"), indent=1, sort_keys=True)
+from build_stamp import build_stamp  # noqa: E402
+json.dump(dict(build=build_stamp(), source="rocprofv3 --kernel-trace --stats -- python3 bench.py (benchmarked concurrent replay)", kernels=out), open(sys.argv[2], "w"), indent=1, sort_keys=True)
 top = sorted(out.items(), key=lambda kv: -kv[1]["share_of_kernel_time"])[:6]
 print(f"{len(out)} kernel names -> {sys.argv[2]}; top: " + ", ".join(f"{k} {v['share_of_kernel_time']:.3f} ({v['avg_launch_ms']*1e3:.1f} us)" for k, v in top))

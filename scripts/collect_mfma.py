@@ -52,7 +52,8 @@ for k, c in sorted(acc.items()):
     if mf is not None and cu and (k.startswith("conv") or k in ("front_fused", "c2f2_fused") or k.startswith("c2f")):
         tot_busy += mf * n
         tot_cu += cu * n
-res = dict(conv_mfma_util=round(tot_busy / (4.0 * tot_cu), 4) if tot_cu else None,
+from build_stamp import build_stamp  # noqa: E402
+res = dict(build=build_stamp(), conv_mfma_util=round(tot_busy / (4.0 * tot_cu), 4) if tot_cu else None,
            definition="sum over conv kernels of SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)", kernels=out)
 json.dump(res, open(sys.argv[1], "w"), indent=1, sort_keys=True)
 print(f"{len(out)} kernels, conv_mfma_util = {res['conv_mfma_util']} -> {sys.argv[1]}")

@@ -34,5 +34,7 @@ for name, a in acc.items():
     fs, ws = a["fetch"] / a["n"], a["write"] / a["n"]
     out[name] = dict(symbols=sorted(a["symbols"]), launches=a["n"], fetch_kib_raw=round(fs, 1), write_kib=round(ws, 1),
                      hbm_bytes_per_launch=int((2.0 * fs + ws) * 1024))
+from build_stamp import build_stamp  # noqa: E402
+out["_build"] = build_stamp()      # (not a kernel name: which build the counters describe)
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print(f"{len(out)} kernels -> {sys.argv[3]}")

@@ -78,3 +78,33 @@ def test_no_cpu_fallback(lib, blob):
     assert ei.value.code == capi.ERR_HIP
     with pytest.raises(capi.IrmvError):
         PnPSolver([1, 0, 0, 0, 1, 0, 0, 0, 1], [0] * 5)
+
+
+def test_numa_cpulist_parser_and_thread_binding(lib):
+    """Host-side NUMA placement (csrc/numa.hpp): the sysfs cpulist parser, and binding a thread to a node's CPUs within the
+    process's own cpuset.  Runs in a child process: affinity is per thread, and the test runner's must stay as it is."""
+    assert capi.numa_parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert capi.numa_parse_cpulist("5") == [5]
+    assert capi.numa_parse_cpulist("") == [] and capi.numa_parse_cpulist("\n") == []
+    assert capi.numa_parse_cpulist("0-1, 4-5") == [0, 1, 4, 5]
+    assert capi.numa_parse_cpulist("3-1") == []                    # malformed range: nothing is bound rather than something wrong
+    assert capi.numa_parse_cpulist("0-2,x,7") == [0, 1, 2]         # parsing stops at the first thing it does not understand
+    assert len(capi.numa_parse_cpulist("0-127")) == 128
+    node0 = "/sys/devices/system/node/node0/cpulist"
+    if not os.path.exists(node0):
+        pytest.skip("no NUMA topology in sysfs")
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from irmv_detection_amd import capi\n"
+            "L = capi.load()\n"
+            "before = os.sched_getaffinity(0)\n"
+            "want = set(capi.numa_parse_cpulist(open(%r).read())) & before\n"
+            "rc = L.irmv_numa_bind_thread(0)\n"
+            "after = os.sched_getaffinity(0)\n"
+            "assert (rc == 0 and after == want) or (rc != 0 and after == before and not want), (rc, before, after, want)\n"
+            "assert L.irmv_numa_bind_thread(4095) != 0 and os.sched_getaffinity(0) == after\n"   # no such node: refused, nothing changed
+            "buf = bytearray(8192); import ctypes as C\n"
+            "n = L.irmv_numa_page_node(C.addressof(C.c_char.from_buffer(buf)))\n"
+            "assert n >= -1\n"
+            "print('ok', rc, sorted(after)[:4], n)\n") % (ROOT, node0)
+    out = subprocess.check_output([os.sys.executable, "-c", code], text=True)
+    assert out.startswith("ok")

@@ -11,6 +11,7 @@ import ctypes as C
 import json
 import multiprocessing as mp
 import os
+import time
 import re
 import subprocess
 
@@ -91,7 +92,24 @@ def test_file_channel_reductions_between_two_processes(tmp_path):
         p.join(30)
         assert p.exitcode == 0
     assert got[0] == got[1] == [[1.0, 2.0], [10.0, 20.0], [0.5, 0.5], [0.0, 1.0]]
-    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("chan.r")) == ["chan.r5.0", "chan.r5.1"]   # only the closing handshake's files stay
+    assert [f for f in os.listdir(tmp_path) if f.startswith("chan.r")] == []   # two closing rounds, then rank 0 sweeps the launch's prefix: nothing stays
+
+
+def test_a_stale_id_file_is_not_accepted(tmp_path):
+    """A file left by an earlier launch that shared the launcher pid and port (crash before cleanup): a non-root rank ignores
+    it -- it is older than the rank itself by more than STALE_S -- and takes the fresh one; the nonce rank 0 appends keys the
+    reduction files of THIS launch."""
+    path = str(tmp_path / "id")
+    with open(path, "wb") as f:
+        f.write(bytes([7]) * comm.ID_BYTES + b"0" * comm.NONCE_BYTES)
+    old = time.time() - comm.STALE_S - 3600
+    os.utime(path, (old, old))
+    with pytest.raises(comm.CommError):
+        comm.exchange_id(1, lambda: b"", path, timeout_s=0.3)
+    uid = bytes(range(128))
+    got, nonce = comm.exchange_id(0, lambda: uid, path, with_nonce=True)
+    assert got == uid and len(nonce) == comm.NONCE_BYTES
+    assert comm.exchange_id(1, lambda: b"", path, timeout_s=5, with_nonce=True) == (uid, nonce)
 
 
 def test_one_rank_is_the_identity(monkeypatch):

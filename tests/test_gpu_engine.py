@@ -38,7 +38,17 @@ SCORE_TOL = 5e-3
 
 
 def BOX_TOL(stride):
+    """Unconstrained frames only (a DFL expectation moves by up to ~0.04 bins under a 3e-2 logit error: 1.3 px at stride 32)."""
     return max(0.5, 0.05 * stride)
+
+
+MARGIN_BOX_TOL = 0.5    # SURVEY 8c's own bar, asserted where it holds: the margin fixtures (measured 0.11 / 0.38 / 0.36 px at strides 8 / 16 / 32)
+
+
+def _report_head(tag, err):
+    """Every parity test prints the head's max |d| vs the fp32 oracle: the headroom under HEAD_TOL is tracked per round in the test log."""
+    print(f"head max|d| vs fp32 oracle [{tag}]: {err:.4f} (tolerance {HEAD_TOL})")
+    return err
 
 
 def _stride(anchor):
@@ -109,7 +119,7 @@ def test_network_taps_and_head_vs_oracle(eng, onet, frame0):
         assert np.abs(t_g - t_o).max() <= 2 * HEAD_TOL, tap     # fp16-emulating oracle: see the module docstring
         assert np.abs(t_g - t_o).mean() <= 2e-3, tap
     h_g = eng.read_head(0)
-    assert np.abs(h_g - onet.forward(x)).max() <= HEAD_TOL                            # vs the fp32 oracle: the contract
+    assert _report_head("frame 0, 640 net", float(np.abs(h_g - onet.forward(x)).max())) <= HEAD_TOL   # vs the fp32 oracle: the contract
     assert np.abs(h_g - onet.forward(x, emulate_fp16=True)).max() <= 2 * HEAD_TOL     # vs another fp16 pipeline
 
 
@@ -126,7 +136,7 @@ def test_network_on_golden_block_input(blob, onet):
         taps = {t: e.read_tap(t, 0) for t in ("0", "2", "4", "9", "15", "21")}
     assert np.array_equal(xin, (img.astype(np.float32) / np.float32(255)).astype(np.float16).astype(np.float32).transpose(2, 0, 1))
     head_o = onet.forward(xin)
-    assert np.abs(head - head_o).max() <= HEAD_TOL
+    assert _report_head("golden 64 x 64 crop", float(np.abs(head - head_o).max())) <= HEAD_TOL
     for t, v in taps.items():
         _, to = onet.forward(xin, tap=t)
         assert np.abs(v - to).max() <= HEAD_TOL, t
@@ -281,7 +291,7 @@ def test_margin_fixtures_survivor_set_identical_end_to_end(blob):
             dk = float(np.abs(raw["kpts"][i] - np.array(c["kpts"][i], np.float32)).max())
             w = worst[_stride(a)]
             w[0], w[1] = max(w[0], db), max(w[1], dk)
-            assert db <= BOX_TOL(_stride(a)), (c["frame"], a, db)
+            assert db <= MARGIN_BOX_TOL, (c["frame"], a, db)    # SURVEY's 0.5 px, at every stride
             assert dk <= KPT_TOL, (c["frame"], a, dk)
             assert abs(float(raw["scores"][i]) - c["scores"][i]) <= SCORE_TOL
     print("margin fixtures: max |d box|, |d kpt| px per stride:", worst)
@@ -332,6 +342,11 @@ def test_visualize_bboxes(eng, frame0):
     img = frame0.copy()
     eng.visualize_bboxes(img, [bbox((100.0, 100.0, 200.0, 180.0), 0.9, ArmorClass.B3), bbox((300.0, 300.0, 400.0, 380.0), 0.9, ArmorClass.R1)])
     assert (img[100, 100:201] == (0, 0, 255)).all() and (img[300, 300:401] == (255, 0, 0)).all()
+    # the class label (src/yolo_engine.cpp:238-241): text origin = the box's top-left corner, glyphs 15 x 21 px above it.
+    # 'B' starts with a filled top row of four cells; 'R1': the '1' glyph's first row is the single cell of column 2
+    assert (img[79:82, 100:112] == (0, 0, 255)).all() and (img[79:82, 112:115] == frame0[79:82, 112:115]).all()
+    assert (img[279:282, 300:312] == (255, 0, 0)).all() and (img[279:282, 324:327] == (255, 0, 0)).all()
+    assert (img[279:282, 318:324] == frame0[279:282, 318:324]).all()
     small = np.zeros((10, 10, 3), np.uint8)
     eng.visualize_bboxes(small, [])                        # size mismatch: message + return (src/yolo_engine.cpp:225-228)
     assert not small.any()
@@ -513,7 +528,8 @@ def test_resident_weight_kernels_are_bitwise_the_chunked_ones(blob, monkeypatch,
 
 @pytest.mark.parametrize("switch", ["IRMV_INLINE_COPIES=1", "IRMV_ZERO_COPY_RESULTS=0", "IRMV_SPLIT_SCAN=0", "IRMV_EMIT_SCAN=0",
                                     "IRMV_FUSED_HEAD=0", "IRMV_MERGE_HEAD0=0", "IRMV_GROUP_HEAD=0", "IRMV_NO_PF2=1", "IRMV_NO_DEEP=1",
-                                    "IRMV_FRONT_FASTX=0", "IRMV_FRONT_DIRECT=0", "IRMV_FRONT_TILE8=0"])
+                                    "IRMV_FRONT_FASTX=0", "IRMV_FRONT_DIRECT=0", "IRMV_FRONT_TILE8=0",
+                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0"])
 def test_every_remaining_switch_is_bitwise_the_default(blob, monkeypatch, switch):
     """The environment switches that select between implementations of the same arithmetic (where the copies ride, where the
     results land, where candidates are found, which launches are merged): heads and detections of a batched step, of
@@ -701,7 +717,7 @@ def test_benchmarked_configuration_is_bitwise_the_single_slot_engine(blob, onet,
     assert not np.array_equal(heads[0], heads[1])
     for s in (0, 63, 127, 128, 191, 255):
         ho = onet.forward(oracle.preprocess(imgs[s], 640))
-        assert np.abs(heads[s] - ho).max() <= HEAD_TOL, s
+        assert _report_head(f"benchmarked configuration, slot {s}", float(np.abs(heads[s] - ho).max())) <= HEAD_TOL, s
         exp = oracle.decode_nms(heads[s], 640, 14, 8)
         assert raws[s]["num_dets"] == exp["num_dets"] and np.array_equal(raws[s]["anchors"], exp["anchors"])
         assert np.array_equal(raws[s]["boxes"], exp["boxes"])
@@ -802,3 +818,42 @@ def test_fused_kernels_are_bitwise_identical(blob, monkeypatch, size, net, mode,
             where = f"head rows {np.nonzero(d.max(1) > 0)[0][:12].tolist()} cols {np.nonzero(d.max(0) > 0)[0][:24].tolist()} max {d.max()}"
     assert not differ, (differ, where, kernels)
     assert np.abs(got[0][0]).max() > 0.1
+
+
+def test_frame_slots_sit_on_the_devices_numa_node(blob):
+    """Multi-GPU host side (SURVEY section 7 "hard parts"): the pinned frame slots are allocated and first touched on the host
+    NUMA node closest to the engine's device; IRMV_NUMA=0 leaves placement to the OS.  Where the box reports no node, or the
+    page query is not permitted, the engine says so and nothing is asserted about pages."""
+    with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3) as e:
+        node, placed = e.numa_node, e.numa_placed
+        pages = [e.src_page_node(s) for s in range(3)]
+        print(f"numa: device node {node}, placed {placed}, slot pages on nodes {pages}")
+        assert node >= -1
+        if node >= 0 and placed and min(pages) >= 0:
+            assert all(p == node for p in pages), (node, pages)
+        e.get_src_image_buffer(0)[:] = frames.synthetic_frame(0)
+        assert len(e.detect(0)) > 0
+
+
+def test_stride2_implementations_are_bitwise_identical(blob, monkeypatch):
+    """The stride-2 layers of the LDS 3x3 family have three implementations the autotuner may pick between -- the LDS kernel,
+    the direct kernel walking K chunk-major on the family's weights, its deep-prefetch form (single-frame steps) -- and
+    IRMV_FORCE_S2 pins one of them: same taps, same head, bit for bit, at a 416 net (52 / 26 / 13 maps: partial tiles)."""
+    img = np.random.default_rng(11).integers(0, 256, (1024, 1280, 3), dtype=np.uint8)
+    res = {}
+    for kind in ("lds", "ct", "deep"):
+        monkeypatch.setenv("IRMV_FORCE_S2", kind)
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, net_size=416) as e:
+            names = [s["name"] for s in e.profile(0, 1) if "s2" in s["name"]]
+            assert len(names) >= 4, names
+            if kind == "lds":
+                assert all("_lds_" in n for n in names), names
+            else:
+                assert sum(n.endswith("_deep_ct" if kind == "deep" else "_ct") for n in names) >= 3, (kind, names)   # (model.3's Cin = 32 layer and model.1 have no LDS-family form to stand in for)
+            _load(e, 0, img)
+            e.detect(0)
+            res[kind] = [e.read_head(0).copy()] + [e.read_tap(t, 0).copy() for t in ("3", "5", "7", "16", "19")]
+    monkeypatch.delenv("IRMV_FORCE_S2")
+    for kind in ("ct", "deep"):
+        for a, b in zip(res["lds"], res[kind]):
+            assert np.array_equal(a, b), kind

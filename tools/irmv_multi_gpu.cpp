@@ -97,7 +97,11 @@ int main(int argc, char **argv)
     std::vector<long> dets(N, 0);
     std::atomic<int> failed{0};
     const int hsteps = std::max(4, steps / 2);
+    std::vector<int> numa_node(N, -1), numa_bound(N, 0);
     auto worker = [&](int r) {
+        // this thread fills GPU r's pinned slots and submits its steps: it runs on the CPUs of that GPU's own socket
+        // (hipDeviceAttributeHostNumaId -> /sys/devices/system/node/nodeK/cpulist), and the engine allocates the slots there
+        if (irmv_numa_device_node(r, &numa_node[r]) == IRMV_OK && numa_node[r] >= 0) numa_bound[r] = irmv_numa_bind_thread(numa_node[r]) == IRMV_OK;
         irmv_engine_cfg cfg;
         irmv_engine_cfg_default(&cfg);
         cfg.device = r; cfg.src_width = sw; cfg.src_height = sh; cfg.num_slots = slots;
@@ -155,6 +159,10 @@ int main(int argc, char **argv)
     for (int r = 0; r < N; r++) printf("%s%.1f", r ? ", " : "", (double)slots * hsteps / t_host[r]);
     printf("], \"detections_last_step\": [");
     for (int r = 0; r < N; r++) printf("%s%ld", r ? ", " : "", dets[r]);
+    printf("], \"numa_node\": [");
+    for (int r = 0; r < N; r++) printf("%s%d", r ? ", " : "", numa_node[r]);
+    printf("], \"numa_thread_bound\": [");
+    for (int r = 0; r < N; r++) printf("%s%d", r ? ", " : "", numa_bound[r]);
     printf("]}\n");
     return 0;
 }
