@@ -134,6 +134,8 @@ def load():
                                      "(python -m irmv_detection_amd._build); there is no CPU fallback")
         L = C.CDLL(path)
         for name, res, args in SYMBOLS:
+            if os.environ.get("IRMV_LIB_PATH") and not hasattr(L, name):
+                continue                    # A/B runs against an OLDER build of the library: entries added since are absent there
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
@@ -168,6 +170,8 @@ def numa_bind_to_device(device: int = 0) -> int:
     """Bind the calling thread to the CPUs of the host NUMA node closest to `device` (multi-GPU runners call this per rank /
     per worker thread BEFORE creating the engine and filling its slots).  Returns the node, or -1 if nothing was bound."""
     node = C.c_int(-1)
+    if not hasattr(load(), "irmv_numa_device_node"):
+        return -1
     if load().irmv_numa_device_node(device, C.byref(node)) != OK or node.value < 0:
         return -1
     return node.value if load().irmv_numa_bind_thread(node.value) == OK else -1

@@ -1029,6 +1029,7 @@ static int build_engine(irmv_engine *e)
     p.iou_thr = c.iou_thr;
     p.max_det = c.max_det;
     p.pre_nms_cap = c.pre_nms_cap;
+    { const char *pf = getenv("IRMV_NMS_PREFILTER"); p.prefilter = (pf && pf[0] == '0') ? 0 : 1; }   // =0: crowded frames sort and mask every candidate (round-3 behaviour; bit-identical)
     if (c.resize_mode == IRMV_RESIZE_STRETCH) {
         p.scale_x = (float)c.src_width / (float)net;   // src/yolo_engine.cpp:155-156
         p.scale_y = (float)c.src_height / (float)net;

@@ -89,40 +89,59 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
     // ---- 1: cv1 (1x1, 32 -> 32, SiLU) on the 20 x 20 region -> y0 (centre only), y1 (whole region) ----
     {
         const float (&bias)[8] = bias_c1;
-        const half_t *xin = a.x + (size_t)b * S * S * a.x_ld;
-        // the block input is read exactly once per workgroup, so its B fragments come straight from memory (zero outside
-        // the image) -- ALL of this wave's tiles at once: loaded tile by tile, each of the 6 - 7 tiles exposed its own
-        // memory round trip
-        constexpr int NT1 = (XN / 16 + 3) / 4;
-        u32x4 Bq[NT1];
+        // The block input is read exactly once per workgroup, so its B fragments come straight from memory -- ALL of this
+        // wave's tiles at once: loaded tile by tile, each of the 6 - 7 tiles exposed its own memory round trip.
+        // Round 4: tiles 0 .. XW - 1 are ROWS of the region (row = the wave-uniform tile index, column = the lane): the row
+        // part of an address is scalar, the column part a per-lane constant; addresses are 32-bit byte offsets from the
+        // (scalar) input pointer; a pixel outside the image reads a clamped pixel and its OUTPUT is forced to zero below
+        // (y1's zero padding), so the loaded fragment needs no select.
+        constexpr int NROWT = XW / 4, NCOLT = (XN / 16 - XW + 3) / 4;      // per wave: 5 row tiles, then 1 or 2 column tiles (XN / 16 - XW = 5 of them)
+        static_assert(XW % 4 == 0 && XW - 16 == 4 && NCOLT == 2, "20 row tiles + 5 column tiles");
+        const char *xbase = reinterpret_cast<const char *>(a.x);
+        const uint32_t img = (uint32_t)b * (uint32_t)(S * S);
+        auto px_off = [&](int gy, int gx) -> uint32_t {                    // byte offset of the (clamped) pixel, this lane's 8 channels
+            const int gyc = gy < 0 ? 0 : (gy >= S ? S - 1 : gy), gxc = gx < 0 ? 0 : (gx >= S ? S - 1 : gx);
+            return ((img + (uint32_t)(gyc * S + gxc)) * (uint32_t)a.x_ld + 8u * g) * 2u;
+        };
+        const int gx_r = ox0 - 2 + r;
+        const bool in_x = (unsigned)gx_r < (unsigned)S;
+        int ly_c[NCOLT], lx_c[NCOLT];
+        bool has_c[NCOLT];
 #pragma unroll
-        for (int i = 0; i < NT1; i++) {
-            const int t = wave + 4 * i;
-            int ly, lx;
-            (void)region_tile_px<XW, XW>(t < XN / 16 ? t : 0, r, ly, lx);
-            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            const bool in = t < XN / 16 && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S;
-            Bq[i] = ld16(xin + ((size_t)(in ? gy : 0) * S + (in ? gx : 0)) * a.x_ld + g * 8);   // zeroed (keep_if) where it is used: the select waits for the load
+        for (int k = 0; k < NCOLT; k++) {                                   // column tile XW + wave + 4 k: pixel q of the 4-wide strip, top to bottom
+            const int tc = wave + 4 * k, q = tc * 16 + r;
+            has_c[k] = tc < XN / 16 - XW;                                   // (wave-uniform; XN / 16 - XW tiles of 16 cover the strip exactly)
+            ly_c[k] = has_c[k] ? q >> 2 : 0;
+            lx_c[k] = 16 + (q & 3);
         }
+        u32x4 Bq[NROWT + NCOLT];
 #pragma unroll
-        for (int i = 0; i < NT1; i++) {
-            const int t = wave + 4 * i;
-            if (t >= XN / 16) break;
-            int ly, lx;
-            (void)region_tile_px<XW, XW>(t, r, ly, lx);      // (XN is a whole number of tiles: every lane has a pixel)
+        for (int i = 0; i < NROWT; i++) Bq[i] = *reinterpret_cast<const u32x4 *>(xbase + px_off(oy0 - 2 + wave + 4 * i, gx_r));
+#pragma unroll
+        for (int k = 0; k < NCOLT; k++) Bq[NROWT + k] = *reinterpret_cast<const u32x4 *>(xbase + px_off(oy0 - 2 + ly_c[k], ox0 - 2 + lx_c[k]));
+        auto run_tile = [&](u32x4 bq, int ly, int lx, bool inside) {
             const int m = ly * XW + lx;
-            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            const half8 B = as_h8(keep_if((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S, Bq[i]));
             f32x4 acc0 = bias4(bias), acc1 = bias4(bias + 4);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[0], B, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[1], B, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[0], as_h8(bq), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc1[1], as_h8(bq), acc1, 0, 0, 0);
             half8 o = zero8;   // outside the image y1 is the bottleneck's zero padding
-            if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S) o = silu_pack8(acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3]);
+            if (inside) o = silu_pack8(acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3]);
             if (g >= 2) {
                 *reinterpret_cast<half8 *>(s_y1 + m * HP + (g - 2) * 16) = o;
             } else if ((unsigned)(ly - 2) < (unsigned)T && (unsigned)(lx - 2) < (unsigned)T) {
                 *reinterpret_cast<half8 *>(s_y0 + ((ly - 2) * T + (lx - 2)) * HP + g * 16) = o;
             }
+        };
+#pragma unroll
+        for (int i = 0; i < NROWT; i++) {
+            const int t = wave + 4 * i, gy = oy0 - 2 + t;                    // wave-uniform
+            run_tile(Bq[i], t, r, in_x && (unsigned)gy < (unsigned)S);
+        }
+#pragma unroll
+        for (int k = 0; k < NCOLT; k++) {
+            if (!has_c[k]) break;
+            const int gy = oy0 - 2 + ly_c[k], gx = ox0 - 2 + lx_c[k];
+            run_tile(Bq[NROWT + k], ly_c[k], lx_c[k], (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S);
         }
     }
     __syncthreads();
@@ -319,51 +338,63 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
 #pragma unroll
             for (int i = 0; i < 8; i++) bias[u * 8 + i] = a.b_cv1[u * 32 + g * 8 + i];
         const int H0 = H >> a.s0.shift, W0 = W >> a.s0.shift, H1 = H >> a.s1.shift, W1s = W >> a.s1.shift;
-        // the block input is read once per workgroup, straight into B fragments; the next tile's loads are in flight under
-        // this tile's MFMAs and SiLU epilogue (a wave walks ~4 tiles: without this each would expose a full memory round trip)
-        auto load_tile = [&](int t, u32x4 (&B)[KS1]) {
-            int ly, lx;
-            (void)region_tile_px<R1H, R1W>(t, r, ly, lx);    // (R1N is a whole number of tiles: every lane has a pixel)
-            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const int gyc = inside ? gy : 0, gxc = inside ? gx : 0;
-            const half_t *p0 = a.s0.p + ((size_t)(b * H0 + (gyc >> a.s0.shift)) * W0 + (gxc >> a.s0.shift)) * a.s0.ld;
-            const half_t *p1 = a.s1.p + ((size_t)(b * H1 + (gyc >> a.s1.shift)) * W1s + (gxc >> a.s1.shift)) * a.s1.ld;
+        // The block input is read once per workgroup, straight into B fragments; the next tile's loads are in flight under
+        // this tile's MFMAs and SiLU epilogue (a wave walks ~4 tiles: without this each would expose a full memory round trip).
+        // Round 4, instruction diet (this phase was 63 % of the kernel's vector instructions, 175 of its 240 per tile index
+        // arithmetic and selects):
+        //  * tiles 0 .. R1H - 1 are ROWS of the region (row = the wave-uniform tile index, column = the lane): the row part of
+        //    every address is scalar, the column part a per-lane constant computed once; only the last tiles (the region's
+        //    four extra columns, walked top to bottom) keep per-lane rows;
+        //  * addresses are a 32-bit byte offset from the segment's (scalar) base pointer: one vector add per fragment instead
+        //    of a 64-bit select + add; which segment a k-step reads is wave-uniform (segment widths are multiples of 32);
+        //  * no select on the loaded fragments: a pixel outside the image reads a clamped (valid, finite) pixel and its
+        //    OUTPUT is forced to zero below -- y1's zero padding -- whatever the MFMAs made of it.
+        constexpr int NT1 = R1N / 16, NROWT = R1H / 4, NCOLT = NT1 - R1H;   // 15 tiles: 12 rows (three per wave) + 3 column tiles (waves 0 .. 2)
+        static_assert(R1H % 4 == 0 && NCOLT >= 0 && NCOLT <= 4 && R1W - 16 == 4, "three row tiles per wave, at most one column tile");
+        const char *base0 = reinterpret_cast<const char *>(a.s0.p), *base1 = reinterpret_cast<const char *>(a.s1.p - a.s0.C);   // (k-step ks of segment 1 sits at channel 32 ks - s0.C)
+        const uint32_t img0 = (uint32_t)b * (uint32_t)(H0 * W0), img1 = (uint32_t)b * (uint32_t)(H1 * W1s);
+        auto px_off = [&](int gyc, int gxc, uint32_t &o0, uint32_t &o1) {           // byte offsets of pixel (gyc, gxc), this lane's 8 channels
+            o0 = ((img0 + (uint32_t)((gyc >> a.s0.shift) * W0 + (gxc >> a.s0.shift))) * (uint32_t)a.s0.ld + 8u * g) * 2u;
+            o1 = ((img1 + (uint32_t)((gyc >> a.s1.shift) * W1s + (gxc >> a.s1.shift))) * (uint32_t)a.s1.ld + 8u * g) * 2u;
+        };
+        auto issue = [&](uint32_t o0, uint32_t o1, u32x4 (&B)[KS1]) {
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) {
-                const int c = ks * 32 + 8 * g;
-                B[ks] = ld16(c < a.s0.C ? p0 + c : p1 + (c - a.s0.C));   // clamped address: always valid; zeroed (keep_if) where it is USED
+                const bool seg0 = ks * 32 < a.s0.C;                                 // wave-uniform
+                B[ks] = *reinterpret_cast<const u32x4 *>((seg0 ? base0 : base1) + ((seg0 ? o0 : o1) + (uint32_t)(ks * 64)));
             }
         };
-        u32x4 Bn[KS1];
-        load_tile(wave, Bn);
-        for (int t = wave; t < R1N / 16; t += 4) {
-            int ly, lx;
-            (void)region_tile_px<R1H, R1W>(t, r, ly, lx);
+        // row tiles: column = lane r, clamped into the image; the row is the tile's
+        const int gx_r = ox0 - 2 + r;
+        const bool in_x = (unsigned)gx_r < (unsigned)W;
+        const int gxc_r = gx_r < 0 ? 0 : (gx_r >= W ? W - 1 : gx_r);
+        auto row_off = [&](int t, uint32_t &o0, uint32_t &o1) {
+            const int gy = oy0 - 2 + t, gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);  // scalar
+            px_off(gyc, gxc_r, o0, o1);
+        };
+        // the column tile of this wave (waves 0 .. NCOLT - 1): pixel q = 16 wave + r of the 4-wide strip, top to bottom
+        const int q_c = 16 * wave + r, ly_c = q_c >> 2, lx_c = 16 + (q_c & 3);
+        const bool has_col = wave < NCOLT;
+        // one tile: fragments B (already loaded), region pixel m = ly * R1W + lx, image pixel (gy, gx)
+        auto run_tile = [&](const u32x4 (&Bq)[KS1], int ly, int lx, bool inside, bool want_y0) {
             const int m = ly * R1W + lx;
             const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            half8 B[KS1];
-#pragma unroll
-            for (int ks = 0; ks < KS1; ks++) B[ks] = as_h8(keep_if(inside, Bn[ks]));   // the select waits for the load: here, not at issue
-            if (t + 4 < R1N / 16) load_tile(t + 4, Bn);
-            // y0 (output tiles 0, 1) is needed on the 8 x 16 tile only: the row tiles of the region's first and last two rows
-            // (one per wave) compute y1 alone -- half the MFMAs and half the SiLUs of those tiles (the wave-uniform branch
-            // costs nothing; nothing of y0 was stored for them anyway)
-            const bool want_y0 = t >= R1H || (t >= 2 && t < R1H - 2);
             f32x4 acc[4];   // tile 2 u + h starts at bias[u * 8 + 4 h ..]
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) acc[nt] = bias4(bias + (nt >> 1) * 8 + (nt & 1) * 4);
+            // y0 (output tiles 0, 1) is needed on the 8 x 16 tile only: the row tiles of the region's first and last two rows
+            // (one per wave) compute y1 alone -- half the MFMAs and half the SiLUs of those tiles (the wave-uniform branch
+            // costs nothing; nothing of y0 was stored for them anyway)
             if (want_y0) {
 #pragma unroll
                 for (int ks = 0; ks < KS1; ks++)
 #pragma unroll
-                    for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[nt][ks], B[ks], acc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[nt][ks], as_h8(Bq[ks]), acc[nt], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < KS1; ks++)
 #pragma unroll
-                    for (int nt = 2; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[nt][ks], B[ks], acc[nt], 0, 0, 0);
+                    for (int nt = 2; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[nt][ks], as_h8(Bq[ks]), acc[nt], 0, 0, 0);
             }
             half8 o[2];
 #pragma unroll
@@ -384,11 +415,40 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
                 if constexpr (MODE == 0) {
                     *reinterpret_cast<half8 *>(s_y0 + (cy * FW + cx) * PS + g * 16) = o[0];
                 } else {
-                    half_t *q = cat + ((size_t)gy * W + gx) * a.cat_ld + g * 8;
-                    *reinterpret_cast<half8 *>(q) = o[0];
-                    *reinterpret_cast<half8 *>(q + 32) = o[1];
+                    half_t *qd = cat + ((size_t)gy * W + gx) * a.cat_ld + g * 8;
+                    *reinterpret_cast<half8 *>(qd) = o[0];
+                    *reinterpret_cast<half8 *>(qd + 32) = o[1];
                 }
             }
+        };
+        u32x4 Bn[KS1], Bc[KS1];
+        {
+            uint32_t o0, o1;
+            row_off(wave, o0, o1);
+            if (!(IRMV_ABL & 1)) issue(o0, o1, Bn);
+        }
+#pragma unroll
+        for (int i = 0; i < NROWT; i++) {
+            const int t = wave + 4 * i;                                             // wave-uniform row of the region
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) Bc[ks] = Bn[ks];
+            {   // the next tile's loads, before this tile's arithmetic
+                uint32_t o0, o1;
+                if (i + 1 < NROWT) {
+                    row_off(t + 4, o0, o1);
+                    if (!(IRMV_ABL & 1)) issue(o0, o1, Bn);
+                } else if (has_col) {
+                    const int gy = oy0 - 2 + ly_c, gx = ox0 - 2 + lx_c;
+                    px_off(gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gx < 0 ? 0 : (gx >= W ? W - 1 : gx), o0, o1);
+                    if (!(IRMV_ABL & 1)) issue(o0, o1, Bn);
+                }
+            }
+            const int gy = oy0 - 2 + t;
+            run_tile(Bc, t, r, in_x && (unsigned)gy < (unsigned)H, t >= 2 && t < R1H - 2);
+        }
+        if (has_col) {
+            const int gy = oy0 - 2 + ly_c, gx = ox0 - 2 + lx_c;
+            run_tile(Bn, ly_c, lx_c, (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W, true);
         }
     } else {
         // y0, y1 of this wave's two output tiles (operands of cv2, phase 4) are fetched NOW: they depend on nothing this

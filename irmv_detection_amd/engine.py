@@ -139,8 +139,9 @@ class YoloEngine:
         self.max_det = max_det
         self.enable_profiling = enable_profiling
         self.num_streams = L.irmv_engine_num_streams(self._h)
-        self.numa_node = L.irmv_engine_numa_node(self._h)            # host NUMA node closest to the device (-1 unknown)
-        self.numa_placed = bool(L.irmv_engine_numa_placed(self._h))  # the pinned frame slots were allocated / first touched there
+        has_numa = hasattr(L, "irmv_engine_numa_node")               # (absent only in an older build loaded through IRMV_LIB_PATH)
+        self.numa_node = L.irmv_engine_numa_node(self._h) if has_numa else -1            # host NUMA node closest to the device (-1 unknown)
+        self.numa_placed = bool(L.irmv_engine_numa_placed(self._h)) if has_numa else False  # the pinned frame slots were allocated / first touched there
         self.num_anchors = L.irmv_engine_num_anchors(self._h)
         self.head_channels = L.irmv_engine_head_channels(self._h)
         self._dets = (capi.Det * max_det)()
