@@ -161,7 +161,7 @@ struct Op {
     int Hin = 0, Win = 0, Hout = 0, Wout = 0, cin = 0, cout = 0, cout_pad = 0, ksteps = 0;
     int out_t = -1, out_coff = 0, res_t = -1, res_coff = 0;
     half_t *w_packed = nullptr;
-    half_t *w_lds[3] = {nullptr, nullptr, nullptr};   // LDS-kernel layout for nt = 1 / 2 / 4 (eligible 3x3 layers only)
+    half_t *w_lds[4] = {nullptr, nullptr, nullptr, nullptr};   // LDS-kernel layout for nt = 1 / 2 / 4 / 8 (eligible 3x3 layers only; nt = 8: stride-2 layers with >= 128 output channels)
     float *bias = nullptr;
     double flops = 0, bytes = 0;  // per frame (bytes: activations in + out, plus the weights)
     double w_bytes = 0;           // the weights' share of `bytes`: read once per LAUNCH, not once per frame (irmv_engine_profile)
@@ -391,9 +391,10 @@ static int pack_conv(irmv_engine *e, const LayerW &l, Op &op)
     // LDS-kernel layout: [n-block][chunk of 32 ch][tap][tile in block][lane][8]
     if (l.k == 3 && l.cin % 32 == 0 && l.act == 1 && !op.cfg.out_f32) {
         const int chunks = l.cin / 32;
-        for (int v = 0; v < 3; v++) {
+        for (int v = 0; v < 4; v++) {
             const int nt = 1 << v;
             if (ntiles % nt != 0 || (nt > 1 && !pair)) continue;
+            if (nt == 8 && l.stride != 2) continue;      // the 128-channel workgroup exists for the stride-2 layers only (k_conv.hip)
             std::vector<uint16_t> pl((size_t)ntiles * chunks * 9 * 512, 0);
             for (int t = 0; t < ntiles; t++)
                 for (int ch = 0; ch < chunks; ch++)
@@ -1282,9 +1283,11 @@ static void tune_cache_save()
         f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0) | (kv.second.pw ? 8 : 0) | (kv.second.pf2 ? 16 : 0) | (kv.second.cm == 2 ? 64 : 0) | (kv.second.cm == 4 ? 128 : 0) | (kv.second.w8 ? 256 : 0) | (kv.second.wr ? 512 : 0) | (kv.second.pp ? 1024 : 0)) << ' ' << kv.second.ipw << '\n';
 }
 
+static int lds_index(int nt) { return nt == 8 ? 3 : (nt == 4 ? 2 : (nt == 2 ? 1 : 0)); }
+
 static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int count, hipStream_t s)
 {
-    const int li = c.nt == 4 ? 2 : (c.nt == 2 ? 1 : 0);
+    const int li = lds_index(c.nt);
     if (c.pw) return launch_conv_pw(c, a, s);
     if (c.wr) return c.lds && op.w_lds[2] && launch_conv_wres(c.ipw, a, op.w_lds[2], count, s, c.pp);
     if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s, c.pf2, c.cm, c.w8);
@@ -1367,7 +1370,7 @@ static int autotune_convs(irmv_engine *e)
                 auto hit = g_tune_cache.find(key);
                 if (hit != g_tune_cache.end() && !verbose && !no_tuning && !(force_s2 && lds_ok && op.cfg.stride == 2)) {
                     const ConvCfg &h = hit->second;
-                    const bool pow2 = (h.mt == 1 || h.mt == 2 || h.mt == 4) && (h.nt == 1 || h.nt == 2 || h.nt == 4) && (h.ipw == 1 || h.ipw == 2 || h.ipw == 4 || (h.wr && h.ipw >= 1));
+                    const bool pow2 = (h.mt == 1 || h.mt == 2 || h.mt == 4) && (h.nt == 1 || h.nt == 2 || h.nt == 4 || (h.nt == 8 && h.w8 && h.mt == 1)) && (h.ipw == 1 || h.ipw == 2 || h.ipw == 4 || (h.wr && h.ipw >= 1));
                     // family: LDS-staged, or (single-frame steps only) its chunk-major stand-in on the direct kernel; never both flags
                     const bool fam_ok = lds_ok ? ((h.lds && !h.ct && !h.deep) || (!h.lds && h.ct && !want_fuse && (!h.deep || counts[pass] == 1)))
                                                : (!h.lds && !h.ct && (!h.deep || counts[pass] == 1 || op.cfg.ks == 1));
@@ -1377,7 +1380,7 @@ static int autotune_convs(irmv_engine *e)
                     if (h.pw && ok && getenv("IRMV_FORCE_PWN") && h.ipw == 1 && (conv_pw_lds_bytes(a, 2) > 0 || conv_pw_lds_bytes(a, 4) > 0)) ok = false;   // (parity tests)
                     if (!h.pw && getenv("IRMV_FORCE_PW") && conv_pw_eligible(op.cfg, a)) ok = false;                                  // (parity tests)
                     if (ok && h.lds && !h.wr) {
-                        const int li = h.nt == 4 ? 2 : (h.nt == 2 ? 1 : 0);
+                        const int li = lds_index(h.nt);
                         ok = op.w_lds[li] && conv_lds_bytes(a, op.cfg.stride, h.mt, h.nt, nullptr, h.w8) > 0;
                     }
                     if (ok && h.wr) ok = !getenv("IRMV_NO_WRES") && h.lds && !h.pf2 && !h.cm && !h.w8 && h.mt == 2 && h.nt == 4 && op.w_lds[2] && conv_wres_bytes(a, op.cfg.stride, h.pp) > 0;
@@ -1386,10 +1389,15 @@ static int autotune_convs(irmv_engine *e)
                     if (ok && h.deep) ok = (h.mt == 1 || (h.mt == 2 && h.nt == 1)) && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1;
                     if (ok && h.ct) ok = op.w_lds[0] != nullptr;
                     if (ok && h.pf2) ok = h.lds && h.mt == 1 && !want_fuse;
-                    if (ok && h.cm) ok = !getenv("IRMV_NO_CM") && h.lds && !h.pf2 && h.cm == h.ipw && h.nt == 4 && ((h.mt == 1 && (!want_fuse || h.cm == 4)) || (h.mt == 2 && h.cm == 2));
-                    if (ok && h.w8) ok = !getenv("IRMV_NO_W8") && h.lds && op.cfg.stride == 2 && h.nt == 4 && !want_fuse && !h.pf2 && (h.mt == 1 || h.mt == 2) &&
-                                         (h.cm == 0 || (h.cm == h.ipw && ((h.mt == 2 && h.cm == 2) || (h.mt == 1 && h.cm == 4))));
+                    if (ok && h.cm && h.nt != 8) ok = !getenv("IRMV_NO_CM") && h.lds && !h.pf2 && h.cm == h.ipw && h.nt == 4 && ((h.mt == 1 && (!want_fuse || h.cm == 4)) || (h.mt == 2 && h.cm == 2));
+                    if (ok && h.w8 && h.nt == 4) ok = !getenv("IRMV_NO_W8") && h.lds && op.cfg.stride == 2 && !want_fuse && !h.pf2 && (h.mt == 1 || h.mt == 2) &&
+                                                     (h.cm == 0 || (h.cm == h.ipw && ((h.mt == 2 && h.cm == 2) || (h.mt == 1 && h.cm == 4))));
+                    if (ok && h.w8 && h.nt == 8) ok = !getenv("IRMV_NO_W8") && !getenv("IRMV_NO_NT8") && h.lds && op.cfg.stride == 2 && !want_fuse && !h.pf2 && h.mt == 1 && op.w_lds[3] &&
+                                                     (h.cm == 0 || (h.cm == 2 && h.ipw == 2));
+                    if (ok && h.w8 && h.nt != 4 && h.nt != 8) ok = false;
+                    if (ok && h.cm && h.nt == 8 && !h.w8) ok = false;
                     if (ok && !h.w8 && getenv("IRMV_FORCE_W8") && lds_ok && op.cfg.stride == 2) ok = false;
+                    if (ok && h.nt != 8 && getenv("IRMV_FORCE_NT8") && lds_ok && op.cfg.stride == 2 && op.w_lds[3] && !want_fuse) ok = false;   // parity tests: the 128-channel workgroup wherever it exists
                     if (ok && !h.cm && getenv("IRMV_FORCE_CM") && lds_ok && counts[pass] >= 2) ok = false;   // parity tests: the chunk-major tiles wherever one exists
                     if (ok) {
                         best_cfg = op.cfg;
@@ -1471,6 +1479,18 @@ static int autotune_convs(irmv_engine *e)
                                 TRY(time_cfg(c));
                                 if (getenv("IRMV_FORCE_W8") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                             }
+                // ... and with all of 128 output channels per workgroup (nt = 8, mt = 1): these layers are bound by what a CU can stage
+                // from L2 (12 B/clk), and the stride-2 patch -- four input pixels per output pixel -- is then fetched once per 128
+                // channels instead of once per 64; chunk-major over two images halves the weight staging on top
+                if (fam == 1 && op.cfg.stride == 2 && !want_fuse && op.cout_pad % 128 == 0 && op.w_lds[3] && !getenv("IRMV_NO_W8") && !getenv("IRMV_NO_NT8"))
+                    for (int ipw = 1; ipw <= std::min(4, counts[pass]); ipw *= 2)
+                        for (int cmv = 0; cmv < 2; cmv++) {
+                            if (cmv && ipw != 2) continue;
+                            ConvCfg c = op.cfg;
+                            c.mt = 1; c.nt = 8; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = cmv ? 2 : 0; c.w8 = true; c.wr = false; c.pp = false;
+                            TRY(time_cfg(c));
+                            if (getenv("IRMV_FORCE_NT8") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
+                        }
                 // LDS family, Cin = Cout = 64, stride 1: resident weights (one 8-wave workgroup per CU walks ipw images at its tile
                 // position; lockstep, or as two ping-pong groups of four waves).  ipw: the smallest that lets the chip hold the
                 // grid in one round, and half of it.

@@ -1460,7 +1460,7 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt, int nwv =
 {   // nwv: the waves that share one patch (ping-pong: half the workgroup's)
     LdsGeom g{false, 0, 0, 0, 0, 0};
     if (a.Cin % 32 != 0 || a.s1.C != 0 || a.s0.shift != 0) return g;
-    if (!((nt == 1) || ((nt == 2 || nt == 4) && a.pair))) return g;
+    if (!((nt == 1) || ((nt == 2 || nt == 4) && a.pair) || (nt == 8 && a.pair && nwv == 8 && stride == 2 && mt == 1))) return g;   // nt = 8: the stride-2 layers' 8-wave workgroup only
     if (a.cout_pad % (16 * nt) != 0) return g;
     int pr, pw;
     const int l2 = a.Wout % 16 == 0 ? 4 : (a.Wout % 8 == 0 ? 3 : (a.Wout % 4 == 0 ? 2 : -1));
@@ -1557,9 +1557,20 @@ bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, con
 {
     if (ipw < 1) ipw = 1;
     if (w8) {   // stride-2 layers: ONE 8-wave workgroup per CU on a block of 128 mt pixels -- see DESIGN section 4
-        if (stride != 2 || nt != 4 || a.n2 > 0 || pf2 || (cm && cm != ipw)) return false;
+        if (stride != 2 || !(nt == 4 || nt == 8) || a.n2 > 0 || pf2 || (cm && cm != ipw)) return false;
         const LdsGeom g8 = lds_geom(a, stride, mt, nt, 8);
         if (!g8.bytes) return false;
+        if (nt == 8) {   // 128 output channels per workgroup: the patch is staged once per 128 channels (mt = 1: 16 pixels x 128 channels per wave)
+#define IRMV_LDS_W8N8(CM_)                                                                                  \
+            if (mt == 1 && cm == CM_) {                                                                     \
+                if (g8.tile2d) launch_lds_inst<2, 1, 8, true, 0, false, CM_, 8>(a, wl, batch, ipw, g8, s);  \
+                else launch_lds_inst<2, 1, 8, false, 0, false, CM_, 8>(a, wl, batch, ipw, g8, s);           \
+                return true;                                                                                \
+            }
+            IRMV_LDS_W8N8(0) IRMV_LDS_W8N8(2)
+#undef IRMV_LDS_W8N8
+            return false;
+        }
 #define IRMV_LDS_W8(MT_, CM_)                                                                            \
         if (mt == MT_ && cm == CM_) {                                                                    \
             if (g8.tile2d) launch_lds_inst<2, MT_, 4, true, 0, false, CM_, 8>(a, wl, batch, ipw, g8, s); \

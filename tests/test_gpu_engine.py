@@ -463,7 +463,7 @@ def test_chunk_major_and_eight_wave_tiles_are_bitwise_the_plain_ones(blob, monke
     a short last group (two images), groups of two three full ones."""
     imgs = [frames.synthetic_frame(60 + i) for i in range(6)]
     heads = {}
-    modes = ("IRMV_FORCE_CM", "IRMV_FORCE_W8", "IRMV_NO_CM")
+    modes = ("IRMV_FORCE_CM", "IRMV_FORCE_W8", "IRMV_FORCE_NT8", "IRMV_NO_CM")   # (NT8: the stride-2 layers with >= 128 output channels on one 128-channel workgroup)
     for mode in modes:
         for m in modes + ("IRMV_NO_W8",):
             monkeypatch.delenv(m, raising=False)
@@ -477,6 +477,8 @@ def test_chunk_major_and_eight_wave_tiles_are_bitwise_the_plain_ones(blob, monke
                 assert n_cm >= 10 and any("_i4_cm" in n for n in names) and any("_cm+1x1" in n for n in names), names
             elif mode == "IRMV_FORCE_W8":
                 assert n_w8 == 5, names                      # the five stride-2 convs
+            elif mode == "IRMV_FORCE_NT8":
+                assert sum("_nt8" in n for n in names) == 3, names   # model.5 / 7 / 19
             else:
                 assert n_cm == 0 and n_w8 == 0, names
             for s, im in enumerate(imgs):
@@ -484,7 +486,7 @@ def test_chunk_major_and_eight_wave_tiles_are_bitwise_the_plain_ones(blob, monke
             e.submit(0, 6); e.wait()
             heads[mode] = [e.read_head(s).copy() for s in range(6)]
             heads[mode + "_taps"] = {t: e.read_tap(t, 5).copy() for t in ("3", "5", "7", "16", "19", "21")}   # the stride-2 convs' outputs, last slot
-    for mode in modes[:2]:
+    for mode in modes[:3]:
         for a, b in zip(heads[mode], heads["IRMV_NO_CM"]):
             assert np.array_equal(a, b), mode
         for k, v in heads[mode + "_taps"].items():
@@ -572,21 +574,25 @@ def test_eight_wave_tiles_on_maps_that_do_not_tile(blob, monkeypatch):
     scheme (no 2-D block divides them), last blocks are partial, the batch's last image group is short (three frames)."""
     imgs = [frames.synthetic_frame(80 + i) for i in range(3)]
     heads = {}
-    for mode in ("IRMV_FORCE_W8", "IRMV_NO_W8"):
-        for m in ("IRMV_FORCE_W8", "IRMV_NO_W8", "IRMV_NO_CM"):
+    for mode in ("IRMV_FORCE_W8", "IRMV_FORCE_NT8", "IRMV_NO_W8"):
+        for m in ("IRMV_FORCE_W8", "IRMV_FORCE_NT8", "IRMV_NO_W8", "IRMV_NO_CM"):
             monkeypatch.delenv(m, raising=False)
         monkeypatch.setenv(mode, "1")
         if mode == "IRMV_NO_W8":
             monkeypatch.setenv("IRMV_NO_CM", "1")
         with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3, num_streams=1, net_size=416) as e:
             names = [st["name"] for st in e.profile(0, 3)]
-            assert (sum("_w8" in n for n in names) == 5) == (mode == "IRMV_FORCE_W8"), (mode, names)
+            if mode == "IRMV_FORCE_NT8":
+                assert sum("_nt8" in n for n in names) == 3, names      # the 128-channel workgroup on model.5 / 7 / 19
+            else:
+                assert (sum("_w8" in n for n in names) == 5) == (mode == "IRMV_FORCE_W8"), (mode, names)
             for s, im in enumerate(imgs):
                 _load(e, s, im)
             e.submit(0, 3); e.wait()
             heads[mode] = [e.read_head(s).copy() for s in range(3)] + [e.read_tap(t, 2).copy() for t in ("3", "5", "7", "16", "19")]
-    for a, b in zip(heads["IRMV_FORCE_W8"], heads["IRMV_NO_W8"]):
-        assert np.array_equal(a, b)
+    for mode in ("IRMV_FORCE_W8", "IRMV_FORCE_NT8"):
+        for a, b in zip(heads[mode], heads["IRMV_NO_W8"]):
+            assert np.array_equal(a, b), mode
 
 
 def test_merged_head_first_stage_is_bitwise_the_separate_convs(blob, frame0, monkeypatch):
