@@ -224,6 +224,7 @@ struct irmv_engine {
     std::map<std::pair<int, int>, SlotGroup> groups;   // (first, count) -> events of that group's last submit
     std::vector<SlotGroup *> slot_owner;               // per slot: the group whose submit touched it last
     bool inline_copies = false;                        // IRMV_INLINE_COPIES=1: round-1 behaviour, copies on the compute stream
+    bool graph_upload = true;                          // uploads that ride the compute stream are a node of the step's graph (IRMV_GRAPH_UPLOAD=0: a separate copy)
     uint8_t *src_host = nullptr;  // pinned [S][frame]
     uint8_t *src_dev = nullptr;   // [S][frame]
     uint8_t *rot_dev = nullptr;   // [frame]
@@ -693,6 +694,7 @@ static int build_engine(irmv_engine *e)
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->h2d_stream, hipStreamNonBlocking));
     { const char *ic = getenv("IRMV_INLINE_COPIES"); e->inline_copies = ic && ic[0] == '1'; }
+    { const char *gu = getenv("IRMV_GRAPH_UPLOAD"); e->graph_upload = !(gu && gu[0] == '0'); }
     e->slot_owner.assign(S, nullptr);
     e->frame_bytes = (size_t)c.src_width * c.src_height * 3;
     {
@@ -1030,7 +1032,8 @@ static int build_engine(irmv_engine *e)
     p.iou_thr = c.iou_thr;
     p.max_det = c.max_det;
     p.pre_nms_cap = c.pre_nms_cap;
-    { const char *pf = getenv("IRMV_NMS_PREFILTER"); p.prefilter = (pf && pf[0] == '0') ? 0 : 1; }   // =0: crowded frames sort and mask every candidate (round-3 behaviour; bit-identical)
+    { const char *pf = getenv("IRMV_NMS_PREFILTER"); p.prefilter = (pf && pf[0] == '0') ? 0 : 1;
+      if (const char *pe = getenv("IRMV_NMS_PRE")) { int hi = 0, lo = 0; if (sscanf(pe, "%d,%d", &hi, &lo) == 2 && hi >= 64 && hi <= 512 && lo >= 32 && lo < hi) p.prefilter = hi | (lo << 16); } }   // experiment: size of the head of the list   // =0: crowded frames sort and mask every candidate (round-3 behaviour; bit-identical)
     if (c.resize_mode == IRMV_RESIZE_STRETCH) {
         p.scale_x = (float)c.src_width / (float)net;   // src/yolo_engine.cpp:155-156
         p.scale_y = (float)c.src_height / (float)net;
@@ -2011,7 +2014,9 @@ static int get_graph(irmv_engine *e, int first, int count, uint32_t flags, bool 
     if (it != e->graphs.end()) { *out = it->second; return IRMV_OK; }
     hipGraph_t g = nullptr;
     HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_step(e, first, count, flags | 0x40000000u, post_only, nullptr);
+    int rc = IRMV_OK;
+    if (flags & 0x10000000u) rc = copy_in(e, first, count, e->stream);   // the frames' upload as the graph's first node (synchronous single-stream submits)
+    if (!rc) rc = enqueue_step(e, first, count, (flags & ~0x10000000u) | 0x40000000u, post_only, nullptr);
     hipError_t ce = hipStreamEndCapture(e->stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (ce != hipSuccess) return fail(IRMV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
@@ -2051,11 +2056,15 @@ static int group_of(irmv_engine *e, int first, int count, SlotGroup **out)
 // overlap with -- keeps everything on one stream, and why the (tiny) download never leaves the compute stream.
 static int submit_group(irmv_engine *e, int f, int c, uint32_t flags, hipStream_t st)
 {
+    const bool async_up = (flags & IRMV_SUBMIT_H2D) && (flags & IRMV_SUBMIT_ASYNC_UPLOAD) && !e->inline_copies;
+    // An upload that rides the compute stream anyway (the synchronous detect()) is captured INTO the step's graph: one
+    // submission instead of two, and the copy -> first kernel hand-over is the graph's own (IRMV_GRAPH_UPLOAD=0: a separate
+    // hipMemcpyAsync in front of the graph, as before; same bits)
+    const bool graph_up = (flags & IRMV_SUBMIT_H2D) && !async_up && e->graph_upload;
     hipGraphExec_t ge;
-    TRY(get_graph(e, f, c, 0, false, &ge));
+    TRY(get_graph(e, f, c, graph_up ? 0x10000000u : 0u, false, &ge));
     SlotGroup *g;
     TRY(group_of(e, f, c, &g));
-    const bool async_up = (flags & IRMV_SUBMIT_H2D) && (flags & IRMV_SUBMIT_ASYNC_UPLOAD) && !e->inline_copies;
     hipStream_t up = async_up ? e->h2d_stream : st;
     // slots last used through a different grouping: order behind that group's completion
     SlotGroup *seen[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -2074,7 +2083,7 @@ static int submit_group(irmv_engine *e, int f, int c, uint32_t flags, hipStream_
             TRY(copy_in(e, f, c, up));
             HIP_TRY(hipEventRecord(g->h2d, up));
             HIP_TRY(hipStreamWaitEvent(st, g->h2d, 0));
-        } else {
+        } else if (!graph_up) {
             TRY(copy_in(e, f, c, st));
         }
     }

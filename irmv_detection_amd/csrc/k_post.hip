@@ -382,12 +382,21 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         // ---- 0'. scan_decode_kernel has filled the frame's key list and decoded the candidate anchors' boxes ----
         // (a lane's first key is requested together with the count, not behind it: one memory round trip instead of two
         // for frames of up to 1024 candidates; beyond the count it is whatever the list holds, and is not used)
-        const unsigned long long k_first = gk[tid < a.key_cap ? tid : 0];
+        // (round 4: ALL eight keys a lane can own in the LDS list are requested with the count -- a crowded frame's 2 000 .. 5 000
+        // keys used to arrive in dependent round trips of 1024, one per loop iteration, ~ 1.5 us each on a single frame)
+        constexpr int KPL = kCandCap / 1024;
+        unsigned long long k_mine[KPL];
+#pragma unroll
+        for (int k = 0; k < KPL; k++) {
+            const int i = tid + k * 1024;
+            k_mine[k] = gk[i < a.key_cap ? i : a.key_cap - 1];
+        }
         int n = a.counts[b];
         n = n < 0 ? 0 : (n > a.key_cap ? a.key_cap : n);           // whatever the counter holds, reads stay inside the list
         if (n <= kCandCap) {
-            if (tid < n) skeys[tid] = k_first;
-            for (int i = tid + blockDim.x; i < n; i += blockDim.x) skeys[i] = gk[i];
+#pragma unroll
+            for (int k = 0; k < KPL; k++)
+                if (tid + k * 1024 < n) skeys[tid + k * 1024] = k_mine[k];
         }
         __syncthreads();                                           // every lane has read the count
         if (tid == 0) { s_ncand = n; a.counts[b] = 0; }            // the next step of this slot starts from zero
@@ -481,7 +490,8 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     // full algorithm's result: a candidate's fate depends only on the candidates before it.  Otherwise (rare: few
     // survivors among the first thousand candidates) ATTEMPT 1 runs the whole list, as before.  A frame of 4 900 candidates
     // decodes, sorts and masks a fifth of them: the NMS kernel's 0.24 ms on such frames was all tail.
-    const bool prefilter_on = a.prefilter != 0 && n_total > kPreHi;
+    const int pre_hi = a.prefilter > 1 ? (a.prefilter & 0xffff) : kPreHi, pre_lo = a.prefilter > 1 ? (a.prefilter >> 16) : kPreLo;   // (> 1: experiment override, hi | lo << 16)
+    const bool prefilter_on = a.prefilter != 0 && n_total > pre_hi;
     int n_stored = n_total, n = 0;
     for (int attempt = prefilter_on ? 0 : 1; attempt < 2; attempt++) {
     n_stored = n_total;
@@ -536,22 +546,29 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         // ---- the frame's best lo .. hi candidates: a radix threshold T with lo <= #{key >= T} <= hi.  MSB first, 8 bits
         // per pass; a pass ends the search as soon as the buckets above the one that would overflow `hi` already hold `lo`
         // keys (usually the first or second pass: any count in [lo, hi] will do, unlike the exact K-th key above) ----
-        constexpr int hi = kPreHi, lo = kPreLo;
+        const int hi = pre_hi, lo = pre_lo;
         unsigned long long prefix = 0ull, mask = 0ull, T = 0ull;
         int above = 0, m = 0;
         for (int pass = 0; pass < 8; pass++) {
             const int shift = 56 - 8 * pass;
-            if (tid < 256) hist[tid] = 0u;
+            // eight copies of every bucket, picked by the lane: candidates all sit above the score threshold, so their keys
+            // share their leading bits and a plain histogram's atomics pile onto two or three LDS words
+            unsigned int *hist8 = reinterpret_cast<unsigned int *>(ssup);          // [256][8] (the masks' buffer: free until phase 2)
+            for (int i = tid; i < 256 * 8; i += blockDim.x) hist8[i] = 0u;
             __syncthreads();
             for (int i = tid; i < n_stored; i += blockDim.x) {
                 const unsigned long long key = skeys[i];
-                if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+                if ((key & mask) == prefix) atomicAdd(&hist8[(((unsigned)(key >> shift) & 255u) << 3) | (lane & 7)], 1u);
             }
             __syncthreads();
             if (wave == 0) {
                 // lane L owns buckets 255 - 4 L .. 252 - 4 L; cumulative counts in descending bucket order
                 const int d0 = 255 - 4 * lane;
-                const unsigned int h0 = hist[d0], h1 = hist[d0 - 1], h2 = hist[d0 - 2], h3 = hist[d0 - 3];
+                auto bucket = [&](int d) {
+                    const uint4 lo = *reinterpret_cast<const uint4 *>(&hist8[d << 3]), hi4 = *reinterpret_cast<const uint4 *>(&hist8[(d << 3) + 4]);
+                    return lo.x + lo.y + lo.z + lo.w + hi4.x + hi4.y + hi4.z + hi4.w;
+                };
+                const unsigned int h0 = bucket(d0), h1 = bucket(d0 - 1), h2 = bucket(d0 - 2), h3 = bucket(d0 - 3);
                 const unsigned int tot = h0 + h1 + h2 + h3;
                 unsigned int inc = tot;
 #pragma unroll
