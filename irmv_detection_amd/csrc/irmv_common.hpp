@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace irmv {
 
@@ -57,6 +58,32 @@ __device__ __forceinline__ half_t silu_add_res(float y, float res)
     float s = p + res;
     asm("" : "+v"(s));
     return (half_t)s;
+}
+
+// Workgroup id -> (tile, image) with all tiles of an image on ONE XCD.  The hardware deals consecutive workgroup ids to the 8
+// XCDs in turn, and each XCD has its own L2: with the plain (tile, image) grid every neighbour of a tile runs on another XCD
+// and re-reads the shared halo from memory (profiles/r04_traffic.json: 1.25 - 1.45 x the algorithmic bytes in the fused C2f kernels, 1.30 x in the front kernel).
+// Here id = 8 j + x  ->  image 8 (j / tiles) + x, tile j % tiles: XCD x walks whole images, their halos meet in its L2.
+// The batch's last (batch % 8) images take the plain order.  `xcd` = 0 switches the mapping off (IRMV_XCD_IMAGES=0).
+__device__ __forceinline__ void tile_image(int id, int tiles, int batch, int xcd, int &tile, int &image)
+{
+    const int full = xcd ? (batch >> 3) * 8 * tiles : 0;
+    if (id < full) {
+        const int j = id >> 3;
+        image = (j / tiles) * 8 + (id & 7);
+        tile = j % tiles;
+    } else {
+        const int r = id - full;
+        image = (full / tiles) + r / tiles;
+        tile = r % tiles;
+    }
+}
+
+// host side: the mapping is on unless IRMV_XCD_IMAGES=0 (read at every launch CALL: engine creation, tuning, graph capture)
+inline int xcd_image_order()
+{
+    const char *v = getenv("IRMV_XCD_IMAGES");
+    return (v && v[0] == '0') ? 0 : 1;
 }
 
 constexpr int kHeadRec = 96;   // fp32 per anchor: box 64 | cls 16 (nc<=16) | kpt 16 (nk<=16)

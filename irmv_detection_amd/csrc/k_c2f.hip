@@ -13,6 +13,7 @@
 // bit-identical to the unfused layers (tests/test_gpu_engine.py::test_fused_kernels_are_bitwise_identical).
 #include "irmv_common.hpp"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace irmv {
@@ -54,7 +55,7 @@ __device__ __forceinline__ bool region_tile_px(int t, int r, int &ly, int &lx)
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
+__global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a, int batch, int xcd)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_y0[T * T * HP];
     __shared__ __attribute__((aligned(16))) uint8_t s_y1[XN * HP];
@@ -62,8 +63,9 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t s_y2[T * T * HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
-    const int b = blockIdx.y;
-    const int tyi = blockIdx.x / a.tiles, txi = blockIdx.x - tyi * a.tiles;
+    int tile_id, b;
+    tile_image(blockIdx.x, a.tiles * a.tiles, batch, xcd, tile_id, b);
+    const int tyi = tile_id / a.tiles, txi = tile_id - tyi * a.tiles;
     const int oy0 = tyi * T, ox0 = txi * T;
     const int S = a.S;
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -244,9 +246,11 @@ __global__ __launch_bounds__(256) void c2f2_kernel(C2fArgs a)
     }
 }
 
+static int c2f_xcd_order() { return xcd_image_order(); }
+
 void launch_c2f2(const C2fArgs &a, int batch, hipStream_t s)
 {
-    hipLaunchKernelGGL(c2f2_kernel, dim3(a.tiles * a.tiles, batch), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(c2f2_kernel, dim3(a.tiles * a.tiles * batch), dim3(256), 0, s, a, batch, c2f_xcd_order());
 }
 
 
@@ -294,7 +298,7 @@ __device__ unsigned long long g_c2f_phase[16];
 #endif
 // MODE 0 = AB, 1 = A, 2 = B.  KS1 = k-steps of cv1 (Cin / 32).
 template <int MODE, int KS1, bool SHORTCUT>
-__global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
+__global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int xcd)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_in = smem;                         // y1 region (modes AB, A) / y_prev region (mode B)
@@ -303,8 +307,9 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a)
     uint8_t *s_y0 = s_yn + R3N * PS;              // y0 on the tile (mode AB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
-    const int b = blockIdx.y;
-    const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
+    int tile_id, b;
+    tile_image(blockIdx.x, a.tiles_x * a.tiles_y, batch, xcd, tile_id, b);
+    const int tyi = tile_id / a.tiles_x, txi = tile_id - tyi * a.tiles_x;
     const int oy0 = tyi * FH, ox0 = txi * FW;
     const int H = a.H, W = a.W;
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -633,7 +638,8 @@ size_t c2f32_lds_bytes(int mode) { return (size_t)(R1N + R2N + (mode == 1 ? 0 : 
 bool launch_c2f32(int mode, bool shortcut, const C2f32Args &a, int batch, hipStream_t s)
 {
     const int ks1 = a.cin1 / 32;
-    const dim3 grid(a.tiles_x * a.tiles_y, batch), block(256);
+    const dim3 grid(a.tiles_x * a.tiles_y * batch), block(256);
+    const int xcd = c2f_xcd_order();
     const size_t lds = c2f32_lds_bytes(mode);
 #define IRMV_C2F32(MODE_, KS_, SC_)                                                                               \
     if (mode == MODE_ && (MODE_ == 2 || ks1 == KS_) && shortcut == SC_) {                                          \
@@ -646,7 +652,7 @@ bool launch_c2f32(int mode, bool shortcut, const C2f32Args &a, int batch, hipStr
                 attr_done |= 1ull << (dev & 63);                                                                   \
             }                                                                                                      \
         }                                                                                                          \
-        hipLaunchKernelGGL((c2f32_kernel<MODE_, KS_, SC_>), grid, block, lds, s, a);                               \
+        hipLaunchKernelGGL((c2f32_kernel<MODE_, KS_, SC_>), grid, block, lds, s, a, batch, xcd);                   \
         return true;                                                                                               \
     }
     IRMV_C2F32(0, 2, true) IRMV_C2F32(0, 2, false) IRMV_C2F32(0, 4, false) IRMV_C2F32(0, 6, false) IRMV_C2F32(0, 6, true) IRMV_C2F32(0, 4, true)

@@ -1426,9 +1426,17 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
 }
 
 template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
-__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch)
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch, int nblocks, int xcd)
 {
-    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+    // 1-D grid, dealt so that every workgroup of an image group -- all its tiles, all its output-channel blocks -- runs on ONE
+    // XCD (irmv_common.hpp tile_image): tiles share halo pixels and channel blocks share the whole input, and with the plain
+    // (tile, group) x block grid those re-reads came from memory, not from the XCD's L2 (1.3 - 1.9 x the input bytes fetched
+    // by the stride-2 and 80 x 80 layers, profiles/r04_traffic.json)
+    const int wg_tiles = PP ? (tiles_x * tiles_y + 1) / 2 : tiles_x * tiles_y, groups = (batch + ipw - 1) / ipw;
+    int rem, grp;
+    tile_image(blockIdx.x, wg_tiles * nblocks, groups, xcd, rem, grp);
+    const int nblk = rem / wg_tiles, tile = rem - nblk * wg_tiles;
+    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, grp * wg_tiles + tile, nblk, wg_tiles * groups, nblocks);
 }
 
 // Several independent 3x3 layers in ONE launch (the Detect branches of the three levels in a single-frame step: fifteen
@@ -1505,8 +1513,9 @@ static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int 
     });
     const int groups = (batch + ipw - 1) / ipw;
     const int wg_tiles = PP ? (g.tiles_x * g.tiles_y + 1) / 2 : g.tiles_x * g.tiles_y;   // ping-pong: two tile positions per workgroup
-    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>), dim3(wg_tiles * groups, a.cout_pad / (16 * NT)), dim3(64 * NWV), g.bytes, s, a,
-                       wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch);
+    const int nblocks = a.cout_pad / (16 * NT);
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>), dim3(wg_tiles * groups * nblocks), dim3(64 * NWV), g.bytes, s, a,
+                       wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch, nblocks, xcd_image_order());
 }
 
 // Weights-resident variant: Cin = 64 -> 64 channels, stride 1.  ONE 8-wave workgroup per CU keeps the

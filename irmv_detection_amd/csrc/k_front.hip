@@ -47,7 +47,7 @@ __device__ unsigned long long g_front_stamps[65536 * 9];   // probe builds: shad
 // 1.15 x / 1.10 x instead of 1.24 x / 1.16 x the pixels, the per-workgroup prologue is paid half as often, and the direct
 // walk fills 93 % of its lane slots instead of 84 %; 38 KB of LDS -> 4 workgroups per CU.
 template <int TY>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5 : 4))) void front_kernel(FrontArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5 : 4))) void front_kernel(FrontArgs a, int batch, int xcd)
 {
     constexpr int C0H = 2 * TY + 1;                      // model.0 output rows the tile needs
     constexpr int INH = 4 * TY + 3;                      // net-input rows those need
@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5
     unsigned long long fst[10];
 #endif
     FSTAMP(0);
-    const int b = blockIdx.y;
-    const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
+    int tile_id, b;   // all tiles of a frame on one XCD: neighbouring tiles' shared source rows then meet in that XCD's L2 (irmv_common.hpp)
+    tile_image(blockIdx.x, a.tiles_x * a.tiles_y, batch, xcd, tile_id, b);
+    const int tyi = tile_id / a.tiles_x, txi = tile_id - tyi * a.tiles_x;
     const int oy0 = tyi * TY, ox0 = txi * TX;
     const int net = a.net, W0 = net >> 1, W1 = net >> 2;
     const int gy0 = 4 * oy0 - 3, gx0 = 4 * ox0 - 3;   // net-input coordinates of s_in[0][0]
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TY == 4 ? 5
 #if IRMV_FSTAMP
     FSTAMP(8);
     if (tid == 0) {
-        const unsigned wg = (blockIdx.y * gridDim.x + blockIdx.x) & 65535u;
+        const unsigned wg = blockIdx.x & 65535u;
         for (int k = 0; k < 9; k++) g_front_stamps[wg * 9 + k] = fst[k];
     }
 #endif
@@ -526,9 +527,10 @@ bool front_prepare()
 bool launch_front(const FrontArgs &a, int batch, hipStream_t s)
 {
     if (a.stage_bytes < front_min_stage_bytes(a.tile_y) || a.stage_bytes > kFrontStageMax) return false;
-    const dim3 grid(a.tiles_x * a.tiles_y, batch);
-    if (a.tile_y == kFrontTileY) hipLaunchKernelGGL(front_kernel<kFrontTileY>, grid, dim3(256), (size_t)a.stage_bytes, s, a);
-    else if (a.tile_y == kFrontTileYDirect && (a.fastx & 2)) hipLaunchKernelGGL(front_kernel<kFrontTileYDirect>, grid, dim3(256), (size_t)a.stage_bytes, s, a);   // the tall tile has no staged path
+    const dim3 grid(a.tiles_x * a.tiles_y * batch);
+    const int xcd = xcd_image_order();
+    if (a.tile_y == kFrontTileY) hipLaunchKernelGGL(front_kernel<kFrontTileY>, grid, dim3(256), (size_t)a.stage_bytes, s, a, batch, xcd);
+    else if (a.tile_y == kFrontTileYDirect && (a.fastx & 2)) hipLaunchKernelGGL(front_kernel<kFrontTileYDirect>, grid, dim3(256), (size_t)a.stage_bytes, s, a, batch, xcd);   // the tall tile has no staged path
     else return false;
     return true;
 }
