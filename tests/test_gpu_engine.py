@@ -938,3 +938,25 @@ def test_crowded_camera_frames_end_to_end_prefilter_on_and_off(blob, monkeypatch
     for fi in (1, 2, 7):
         a, b = out[("1", fi)], out[("0", fi)]
         assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+
+@pytest.mark.parametrize("switch", ["IRMV_SPLIT_SCAN=0", "IRMV_EMIT_SCAN=0"])
+def test_crowded_frames_with_the_other_candidate_sources(blob, monkeypatch, switch):
+    """The first-walk-on-the-head-of-the-list path of nms_pnp_kernel takes its keys from three places: the class-branch conv
+    epilogues (default), scan_decode_kernel (IRMV_EMIT_SCAN=0, and every run_post) and the kernel's own scan
+    (IRMV_SPLIT_SCAN=0: no counters, keys also mirrored to the global list the start-over reloads from).  A head that forces
+    the start-over and a 4 900-candidate camera crop, each against the oracle."""
+    name, val = switch.split("=")
+    monkeypatch.setenv(name, val)
+    head = _clustered_head(np.random.default_rng(5), 1600, 600)
+    with YoloEngine(None, (1280, 1024), weights_blob=blob) as e:
+        raw = _assert_post_exact(e, head)
+        assert raw["n_candidates"] > 1600
+    with YoloEngine(None, (640, 640), weights_blob=blob) as e:
+        _load(e, 0, np.ascontiguousarray(frames.synthetic_frame(1)[:640, :640]))
+        e.detect(0)
+        raw, hd = e.read_raw(0), e.read_head(0)
+        exp = oracle.decode_nms(hd, 640, 14, 8)
+        assert raw["n_candidates"] == exp["n_candidates"] > 4000
+        assert raw["num_dets"] == exp["num_dets"] and np.array_equal(raw["anchors"], exp["anchors"]) and np.array_equal(raw["boxes"], exp["boxes"])
+        assert np.array_equal(raw["scores"], exp["scores"]) and np.array_equal(raw["kpts"], exp["kpts"])
