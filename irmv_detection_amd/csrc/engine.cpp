@@ -289,11 +289,14 @@ irmv_engine::~irmv_engine()
         if (extra_streams[i]) (void)hipStreamSynchronize(extra_streams[i]);
     if (h2d_stream) (void)hipStreamSynchronize(h2d_stream);
     if (dbg_dev) {   // diagnostic: phase cycles of the last nms_pnp launch per slot (100 MHz s_memtime-independent clock64)
-        std::vector<long long> h((size_t)cfg.num_slots * 8);
+        std::vector<long long> h((size_t)cfg.num_slots * 16);
         if (hipMemcpy(h.data(), dbg_dev, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             for (int s = 0; s < cfg.num_slots && s < 4; s++)
-                fprintf(stderr, "[nms stamps] slot %d: keys+decode %lld sort %lld masks %lld walk %lld out+pnp %lld cycles; n=%lld kept=%lld\n", s, h[s * 8 + 7] - h[s * 8 + 0], h[s * 8 + 1] - h[s * 8 + 7],
-                        h[s * 8 + 2] - h[s * 8 + 1], h[s * 8 + 3] - h[s * 8 + 2], h[s * 8 + 4] - h[s * 8 + 3], h[s * 8 + 5], h[s * 8 + 6]);
+            {
+                const long long *t = &h[(size_t)s * 16];
+                fprintf(stderr, "[nms stamps] slot %d: keys %lld select %lld decode %lld sort %lld gather+classes %lld rows %lld walk %lld kpts %lld pnp %lld store %lld cycles; n=%lld kept=%lld\n", s,
+                        t[7] - t[0], t[8] - t[7], t[9] - t[8], t[1] - t[9], t[10] - t[1], t[2] - t[10], t[3] - t[2], t[11] - t[3], t[12] - t[11], t[4] - t[12], t[5], t[6]);
+            }
     }
     for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
     graphs.clear();
@@ -1057,8 +1060,8 @@ static int build_engine(irmv_engine *e)
     p.pnp = e->pnp_dev;
     p.dbg = nullptr;
     if (getenv("IRMV_NMS_STAMPS")) {
-        TRY(dev_alloc(e, (void **)&e->dbg_dev, (size_t)S * 8 * sizeof(long long)));
-        HIP_TRY(hipMemset(e->dbg_dev, 0, (size_t)S * 8 * sizeof(long long)));
+        TRY(dev_alloc(e, (void **)&e->dbg_dev, (size_t)S * 16 * sizeof(long long)));
+        HIP_TRY(hipMemset(e->dbg_dev, 0, (size_t)S * 16 * sizeof(long long)));
         p.dbg = e->dbg_dev;
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -1809,7 +1812,7 @@ static PostArgs post_args(const irmv_engine *e, int first)
     p.key_cap = e->A * e->nc;
     p.dets = (e->zero_copy_results ? e->dets_host_dev : e->dets_dev) + (size_t)first * e->cfg.max_det;
     p.fout = (e->zero_copy_results ? e->fout_host_dev : e->fout_dev) + first;
-    if (p.dbg) p.dbg += (size_t)first * 8;
+    if (p.dbg) p.dbg += (size_t)first * 16;
     p.counts = e->split_scan ? e->cand_counts + first : nullptr;
     return p;
 }

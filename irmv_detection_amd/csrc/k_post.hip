@@ -367,7 +367,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     __shared__ int s_kept;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#define IRMV_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[b * 8 + (k)] = clock64(); } while (0)
+#define IRMV_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[b * 16 + (k)] = clock64(); } while (0)
     IRMV_STAMP(0);
     __shared__ int s_ncand, s_nanch;
     unsigned long long *gk = a.keys + (size_t)b * a.key_cap;
@@ -612,10 +612,12 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         n_stored = m;
         truncated = true;
     }
+    IRMV_STAMP(8);
     if (a.keys_only) {
         decode_keys(skeys, n_stored);
         __syncthreads();                                // boxes visible to the whole workgroup
     }
+    IRMV_STAMP(9);
 
     if (n_stored <= kRankSortUse) {
         // keys are unique, so "number of keys greater than mine" is a permutation.  A key's count is split over P lanes (all
@@ -707,6 +709,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             }
         }
         __syncthreads();
+        IRMV_STAMP(10);
         // Row i of the matrix: bit jj of word w <=> candidate j = 64 w + jj (j < i) has i's class and IoU(j, i) > thr -- who
         // suppresses i if kept.  Rows are built for a range of 64-candidate blocks at a time (see below).
         // (an item is HALF a word: twice the items of half the length spread more evenly over the 1024 lanes -- a row's cost
@@ -949,59 +952,90 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         fo.pad = 0;
         a.fout[b] = fo;
     }
-    // ---- 4. one QUAD of lanes per survivor: the record is assembled redundantly on its four lanes, the fp64 PnP runs
-    // spread over them (solve_pnp_ippe_quad: one undistorted point / one IPPE solution per lane), lane 0 stores ----
-    const int j = tid >> 2;
-    if (j < a.max_det) {          // quad-uniform
-        DevDet d;
-        if (j < kept) {
+    // ---- 4. one PAIR of lanes per survivor: the record is assembled redundantly on both lanes, the fp64 PnP runs spread
+    // over them (solve_pnp_ippe_pair: two undistorted points / one IPPE solution per lane), lane 0 stages the record ----
+    DevDet *sdet = reinterpret_cast<DevDet *>(skeys);   // (the key list is dead: the survivors' keys sit in kept_key)
+    const int j = tid >> 1;
+    {
+        if (j < kept) {           // pair-uniform
+            // the record's fields go to the LDS staging as they are produced (lane 0 of the pair): held in registers across the
+            // solver they spilled
+            DevDet *d = &sdet[j];
+            const bool w = (tid & 1) == 0;
             const f32x4 box = kept_box[j];
             const unsigned long long key = kept_key[j];
             const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
             const int an = anchor_of(id, a.nc, a.A);
             const float logit = unorderable((uint32_t)(key >> 32));
-            d.score = 1.0f / (1.0f + irmv_expf(-logit));
-            d.cls = kept_cls[j];
-            d.anchor = an;
             int ix, iy, s, lbase, lhw, rin;
             anchor_geom(an, a.net, ix, iy, s, lbase, lhw, rin);
             const float axm = ((float)ix + 0.5f) - 0.5f, aym = ((float)iy + 0.5f) - 0.5f, sf = (float)s;
             const float *kp = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin) + kKptOff;
+            float kpv[8];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                d.box_net[i] = box[i];
-                const float off = (i & 1) ? a.off_y : a.off_x, sc = (i & 1) ? a.scale_y : a.scale_x;
-                d.xyxy[i] = (box[i] - off) * sc;
+            for (int q = 0; q < 8; q++) kpv[q] = q < a.nk ? kp[q] : 0.f;
+            if (w) {
+                d->score = 1.0f / (1.0f + irmv_expf(-logit));
+                d->cls = kept_cls[j];
+                d->anchor = an;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    d->box_net[i] = box[i];
+                    const float off = (i & 1) ? a.off_y : a.off_x, sc = (i & 1) ? a.scale_y : a.scale_x;
+                    d->xyxy[i] = (box[i] - off) * sc;
+                }
             }
+            float px0 = 0.f, py0 = 0.f, px1 = 0.f, py1 = 0.f;      // this lane's two points for the solver (q and q + 2)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float kx = 0.f, ky = 0.f;
                 if (2 * q + 1 < a.nk) {
-                    kx = (2.0f * kp[2 * q] + axm) * sf;
-                    ky = (2.0f * kp[2 * q + 1] + aym) * sf;
+                    kx = (2.0f * kpv[2 * q] + axm) * sf;
+                    ky = (2.0f * kpv[2 * q + 1] + aym) * sf;
                 }
-                d.kpts_net[2 * q] = kx;
-                d.kpts_net[2 * q + 1] = ky;
-                d.kpts[2 * q] = (kx - a.off_x) * a.scale_x;
-                d.kpts[2 * q + 1] = (ky - a.off_y) * a.scale_y;
+                const float sx = (kx - a.off_x) * a.scale_x, sy = (ky - a.off_y) * a.scale_y;
+                if ((q & 1) == (tid & 1)) {
+                    if (q < 2) { px0 = sx; py0 = sy; } else { px1 = sx; py1 = sy; }
+                }
+                if (w) {
+                    d->kpts_net[2 * q] = kx;
+                    d->kpts_net[2 * q + 1] = ky;
+                    d->kpts[2 * q] = sx;
+                    d->kpts[2 * q + 1] = sy;
+                }
             }
-            for (int i = 0; i < 3; i++) { d.rvec[i] = 0.0; d.tvec[i] = 0.0; }
-            d.quat[0] = d.quat[1] = d.quat[2] = 0.0; d.quat[3] = 1.0;
-            d.pnp_ok = 0;
-            d.armor_valid = a.nk >= 8 ? 1 : 0;   // keypoint head: every detection carries its four points
-            d.armor_size = a.armor_size;
-            d.n_lights = 0;
-            if (a.nk >= 8) d.pnp_ok = solve_pnp_ippe_quad(*a.pnp, d.kpts, a.armor_size, d.rvec, d.tvec, d.quat) ? 1 : 0;
-        } else {
-            // EfficientNMS zero-pads its outputs
-            unsigned char *z = reinterpret_cast<unsigned char *>(&d);
-            for (unsigned i = 0; i < sizeof(DevDet); i++) z[i] = 0;
+            IRMV_STAMP(11);
+            double rvec[3] = {0.0, 0.0, 0.0}, tvec[3] = {0.0, 0.0, 0.0}, quat[4] = {0.0, 0.0, 0.0, 1.0};
+            int pnp_ok = 0;
+            if (a.nk >= 8) pnp_ok = solve_pnp_ippe_pair(*a.pnp, px0, py0, px1, py1, a.armor_size, rvec, tvec, quat) ? 1 : 0;
+            IRMV_STAMP(12);
+            if (w) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) { d->rvec[i] = rvec[i]; d->tvec[i] = tvec[i]; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) d->quat[i] = quat[i];
+                d->pnp_ok = pnp_ok;
+                d->armor_valid = a.nk >= 8 ? 1 : 0;   // keypoint head: every detection carries its four points
+                d->armor_size = a.armor_size;
+                d->n_lights = 0;
+                d->pad_ = 0;
+            }
         }
-        if ((tid & 3) == 0) a.dets[(size_t)b * a.max_det + j] = d;
     }
     __syncthreads();
+    // The frame's records leave as ONE contiguous run of 16-byte stores (13 per record), zero-padded behind the last
+    // survivor as EfficientNMS pads its outputs.  (One lane per record storing its own 208
+    // bytes put 16 different cache lines under every store instruction: 4 us of a 38 us frame went into that.)
+    {
+        static_assert(sizeof(DevDet) % 16 == 0 && sizeof(DevDet) * kMaxDetCap <= sizeof(skeys), "record staging");
+        constexpr int kVec = sizeof(DevDet) / 16;
+        const u32x4_t *src = reinterpret_cast<const u32x4_t *>(sdet);
+        u32x4_t *dst = reinterpret_cast<u32x4_t *>(a.dets + (size_t)b * a.max_det);
+        const u32x4_t zero = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < a.max_det * kVec; i += blockDim.x) dst[i] = i < kept * kVec ? src[i] : zero;
+    }
     IRMV_STAMP(4);
-    if (a.dbg && tid == 0) { a.dbg[b * 8 + 5] = n_total; a.dbg[b * 8 + 6] = kept; }
+    if (a.dbg && tid == 0) { a.dbg[b * 16 + 5] = n_total; a.dbg[b * 16 + 6] = kept; }
 #undef IRMV_STAMP
 }
 

@@ -190,34 +190,46 @@ __device__ inline bool solve_pnp_ippe(const PnpConst &c, const float *pts, int a
     return chk == chk && fabs(chk) < 1e300;
 }
 
-// The same solver spread over a QUAD of lanes (4 consecutive lanes, all active, same arguments; the result is valid on
-// every lane of the quad).  The two data-parallel parts run one item per lane -- the four points of the iterative
-// undistortion, the two IPPE solutions -- everything else is computed redundantly in lockstep.  Per point / per solution
-// the operation sequence is the one of solve_pnp_ippe(), so the results are bit-identical to it; degenerate inputs are
-// carried as a flag instead of early returns so that the shuffles stay converged.
+// The same solver spread over a PAIR of lanes (2 consecutive lanes, both active, same arguments; the result is valid on both).
+// The two data-parallel parts run split over the pair -- points q and q + 2 of the iterative undistortion, IPPE solution q --
+// everything else is computed redundantly in lockstep.  Per point / per solution the operation sequence is the one of
+// solve_pnp_ippe(), so the results are bit-identical to it; degenerate inputs are carried as a flag instead of early returns
+// so that the shuffles stay converged.
+// (Round 4: a pair, not a quad.  The solver is ~ 1 300 fp64 instructions at 4 issue cycles each: ISSUE bound, so what counts is
+// how many waves share a SIMD.  A hundred survivors on quads are seven waves, two to a SIMD: 12 k cycles; on pairs they are
+// four waves, one per SIMD, each ~ 150 instructions longer: 7 k.)
 __device__ inline double quad_bcast(double v, int src_lane) { return __shfl(v, src_lane); }
 
-__device__ inline bool solve_pnp_ippe_quad(const PnpConst &c, const float *pts, int armor_size, double *rvec, double *tvec, double *quat)
+// (px[h], py[h]): point q + 2 h of the armor (LB, LT, RT, RB) in source-frame pixels -- BY VALUE: a pointer indexed by the lane
+// parity had put the caller's array (and with it the whole record) into scratch memory
+__device__ inline bool solve_pnp_ippe_pair(const PnpConst &c, float px0, float py0, float px1, float py1, int armor_size, double *rvec, double *tvec, double *quat)
 {
-    const int lane = threadIdx.x & 63, base = lane & ~3, q = lane & 3;
+    const int lane = threadIdx.x & 63, base = lane & ~1, q = lane & 1;
     const double hy = c.hy[armor_size], hz = c.hz[armor_size];
     bool ok = true;
     double nxy[8];
-    {   // point q on this lane (undistort4's loop body)
-        const double x0 = ((double)pts[2 * q] - c.cx) / c.fx, y0 = ((double)pts[2 * q + 1] - c.cy) / c.fy;
-        double x = x0, y = y0;
-        for (int it = 0; it < 5; it++) {
-            const double r2 = x * x + y * y;
-            const double icd = 1.0 / (1.0 + ((c.k3 * r2 + c.k2) * r2 + c.k1) * r2);
-            const double dx = 2.0 * c.p1 * x * y + c.p2 * (r2 + 2.0 * x * x);
-            const double dy = c.p1 * (r2 + 2.0 * y * y) + 2.0 * c.p2 * x * y;
-            x = (x0 - dx) * icd;
-            y = (y0 - dy) * icd;
+    {   // points q and q + 2 on this lane (undistort4's loop body, the two chains interleaved by the scheduler)
+        double xs[2], ys[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float px = h ? px1 : px0, py = h ? py1 : py0;
+            const double x0 = ((double)px - c.cx) / c.fx, y0 = ((double)py - c.cy) / c.fy;
+            double x = x0, y = y0;
+            for (int it = 0; it < 5; it++) {
+                const double r2 = x * x + y * y;
+                const double icd = 1.0 / (1.0 + ((c.k3 * r2 + c.k2) * r2 + c.k1) * r2);
+                const double dx = 2.0 * c.p1 * x * y + c.p2 * (r2 + 2.0 * x * x);
+                const double dy = c.p1 * (r2 + 2.0 * y * y) + 2.0 * c.p2 * x * y;
+                x = (x0 - dx) * icd;
+                y = (y0 - dy) * icd;
+            }
+            xs[h] = x;
+            ys[h] = y;
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            nxy[2 * i] = quad_bcast(x, base + i);
-            nxy[2 * i + 1] = quad_bcast(y, base + i);
+        for (int i = 0; i < 4; i++) {           // point i sits on lane (i & 1), slot (i >> 1)
+            nxy[2 * i] = quad_bcast(xs[i >> 1], base + (i & 1));
+            nxy[2 * i + 1] = quad_bcast(ys[i >> 1], base + (i & 1));
         }
     }
     const double cX[4] = {hy, hy, -hy, -hy}, cY[4] = {-hz, hz, hz, -hz};
@@ -264,11 +276,11 @@ __device__ inline bool solve_pnp_ippe_quad(const PnpConst &c, const float *pts, 
     double bb1 = sqrt(fmax(1.0 - r01 * r01 - r11 * r11, 0.0));
     if (-r00 * r01 - r10 * r11 < 0.0) bb1 = -bb1;
 
-    // solution (q & 1) on this lane
+    // solution q on this lane
     Pose ps;
     bool sol_ok;
     {
-        const int sol = q & 1;
+        const int sol = q;
         const double c0 = sol ? -bb0 : bb0, c1 = sol ? -bb1 : bb1;
         const double m[9] = {r00, r01, r10 * c1 - c0 * r11, r10, r11, c0 * r01 - r00 * c1, c0, c1, r00 * r11 - r01 * r10};
         double Rc[9];
