@@ -209,6 +209,7 @@ struct irmv_engine {
     // conv3x3_lds_multi / conv_mfma_multi).  family 0: LDS 3x3 with tile (mt 1, nt); 1: direct kernel with cfg.
     struct HeadGroup { std::vector<int> members; int family = 0, nt = 1; ConvCfg cfg{}; char name[48] = {0}; };
     std::vector<HeadGroup> head_groups;
+    bool post_keys_only = false;   // IRMV_POST_KEYS_ONLY=1 (tests): run_post's NMS ignores scan_decode_kernel's boxes and decodes its own, as a whole step's does
     bool emit_scan = false;   // candidates are emitted by the class-branch conv epilogues (needs split_scan's counters and all three levels fused)
     int emit_level_abase[3] = {0, 0, 0};
     bool split_scan = true;   // scan + box decode as a multi-workgroup kernel in front of nms_pnp (IRMV_SPLIT_SCAN=0: inside it)
@@ -1035,6 +1036,8 @@ static int build_engine(irmv_engine *e)
     p.iou_thr = c.iou_thr;
     p.max_det = c.max_det;
     p.pre_nms_cap = c.pre_nms_cap;
+    { const char *pk = getenv("IRMV_POST_KEYS_ONLY"); e->post_keys_only = pk && pk[0] == '1'; }
+    { const char *cw = getenv("IRMV_NMS_CLASSWALK"); p.classwalk = (cw && cw[0] == '0') ? 0 : 1; }
     { const char *pf = getenv("IRMV_NMS_PREFILTER"); p.prefilter = (pf && pf[0] == '0') ? 0 : 1;
       if (const char *pe = getenv("IRMV_NMS_PRE")) { int hi = 0, lo = 0; if (sscanf(pe, "%d,%d", &hi, &lo) == 2 && hi >= 64 && hi <= 512 && lo >= 32 && lo < hi) p.prefilter = hi | (lo << 16); } }   // experiment: size of the head of the list   // =0: crowded frames sort and mask every candidate (round-3 behaviour; bit-identical)
     if (c.resize_mode == IRMV_RESIZE_STRETCH) {
@@ -1969,7 +1972,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         case OP_SCAN: launch_scan_decode(pa, count, s); break;
         case OP_NMS: {
             PostArgs pn = pa;
-            pn.keys_only = (e->emit_scan && !post_only) ? 1 : 0;
+            pn.keys_only = ((e->emit_scan && !post_only) || (post_only && e->post_keys_only)) ? 1 : 0;
             launch_nms_pnp(pn, count, s);
             break;
         }

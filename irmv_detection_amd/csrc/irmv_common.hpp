@@ -323,6 +323,7 @@ struct PostArgs {
     int keys_only;            // 1: the key list comes from the class-branch conv epilogues (ConvArgs::scan_keys): nms_pnp_kernel decodes
                               // the candidates' boxes itself
     int prefilter;            // 1: frames with more than 512 candidates first walk their best 320 .. 512 only (exact: nms_pnp_kernel, "ATTEMPT 0")
+    int classwalk;            // 1: frames of up to 512 candidates take nms_pnp_kernel's class-major path (round 4); 0: the round-3 matrix walk (bit-identical)
     int *counts;              // [B] candidates appended by scan_decode_kernel; nullptr: nms_pnp_kernel scans the head itself.
                               // Zero at engine creation; nms_pnp_kernel reads its frame's count and resets it (no memset node, nothing
                               // for another step to find non-zero); every reader clamps it to key_cap

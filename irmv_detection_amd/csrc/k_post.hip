@@ -291,6 +291,21 @@ __device__ __forceinline__ bool iou_gt(const f32x4 a, const f32x4 b, float thr)
     return inter > thr * uni;
 }
 
+// the same test with the two areas handed in ((a[2] - a[0]) * (a[3] - a[1]), computed once per box): same operations, same bits
+__device__ __forceinline__ bool iou_gt_area(const f32x4 a, float aa, const f32x4 b, float ab, float thr)
+{
+    const float ix1 = a[0] > b[0] ? a[0] : b[0];
+    const float iy1 = a[1] > b[1] ? a[1] : b[1];
+    const float ix2 = a[2] < b[2] ? a[2] : b[2];
+    const float iy2 = a[3] < b[3] ? a[3] : b[3];
+    float iw = ix2 - ix1, ih = iy2 - iy1;
+    iw = iw > 0.0f ? iw : 0.0f;
+    ih = ih > 0.0f ? ih : 0.0f;
+    const float inter = iw * ih;
+    const float uni = (aa + ab) - inter;
+    return inter > thr * uni;
+}
+
 __global__ void pnp_only_kernel(PnpConst c, const float *pts, int n, int armor_size, double *rvec, double *tvec, int32_t *ok)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,6 +341,8 @@ constexpr int kLazyN_ = 1024;   // most candidates of the lazy-matrix walk
 // A crowded frame's first attempt works on the best kPreLo .. kPreHi candidates: <= 512 = the full-matrix walk, the fastest
 // path there is (on the benchmark's frames the hundredth survivor sits among the first ~ 300 candidates)
 constexpr int kPreHi = 512, kPreLo = 320;
+constexpr int kMatW_ = 8;       // 64-bit words of a suppression-matrix row (512 candidates)
+constexpr int kKptLds = 6144;   // class-walk path: the candidates' keypoint logits live in skeys[kKptLds ..) (16 KiB)
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -493,6 +510,11 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     const int pre_hi = a.prefilter > 1 ? (a.prefilter & 0xffff) : kPreHi, pre_lo = a.prefilter > 1 ? (a.prefilter >> 16) : kPreLo;   // (> 1: experiment override, hi | lo << 16)
     const bool prefilter_on = a.prefilter != 0 && n_total > pre_hi;
     int n_stored = n_total, n = 0;
+    constexpr int kLazyW = kLazyN_ / 64;
+    __shared__ unsigned long long s_keptw[kLazyW];        // per 64-candidate block: its survivors
+    __shared__ unsigned long long s_clsmask[16][kLazyW];  // per class and block: which candidates have that class
+    bool kp_lds = false;                                  // the survivors' keypoint logits sit in LDS (class-walk path)
+    __shared__ int s_cbase[16], s_ccnt[16], s_W;
     for (int attempt = prefilter_on ? 0 : 1; attempt < 2; attempt++) {
     n_stored = n_total;
     if (attempt == 1 && prefilter_on) {            // start over on the whole list
@@ -613,6 +635,244 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         truncated = true;
     }
     IRMV_STAMP(8);
+    kp_lds = a.keys_only && a.classwalk && n_stored <= kRankSortUse;
+    if (kp_lds) {
+    // ================= up to 512 candidates whose boxes nobody has decoded yet: the usual frame (round 4) =================
+    // Same algorithm, reorganised around three observations.  (1) A candidate's box is needed at its RANK, not at its anchor:
+    // the keys are sorted first, the boxes are decoded in score order straight into LDS and the keypoint logits come with
+    // them -- no store to and gather from the global box list (two memory round trips, ~ 2 us each on a lone frame), no
+    // keypoint read after the walk (a third).  (Requesting the logits BEFORE the sort, to run it under their round trip, was
+    // built first: 32 more registers across the sort loop spilled eighteen values to scratch memory all over the kernel.)  (2) Suppression is class-aware, so the walk of one class never looks at
+    // another: candidates are regrouped class-major (score order kept inside a class), the IoU tests of a row are then a
+    // DENSE run over the class's earlier members (no per-word class filter and bit loop: rows of different classes in one
+    // wave made every wave wait for its longest loop), and the sixteen waves walk the sixteen classes side by side.  (3) The
+    // max_det cap cuts the survivors in SCORE order whatever order they were found in: survivors are flagged at their
+    // score-order position and counted off there.  Comparisons, operands and their order are the oracle's: bit-identical
+    // (tests: every parity test runs this path; IRMV_NMS_CLASSWALK=0 is the round-3 path, compared bitwise).
+    {
+        f32x4 *cbox = &stage_box[0][0], *mbox = cbox + kRankSortUse;   // boxes in score order / class-major order
+        int *ccls = &stage_cls[0][0], *minfo = ccls + kRankSortUse;    // class in score order / (score position << 8 | class), class-major
+        float *marea = reinterpret_cast<float *>(srank + kRankSortUse); // box areas, class-major (srank holds 512 sorted keys here)
+        float *ckpt = reinterpret_cast<float *>(skeys + kKptLds);       // keypoint logits in score order, 8 per candidate
+        unsigned short *kept_src = &cls_list[0][0];                     // survivor -> score position (the per-class lists are not used here)
+        // (lane numbers behind an opaque copy: the address arithmetic of this path, hoisted out of the attempt loop as loop
+        // invariants, had seven values spilled to scratch memory at the loop's head and reloaded here)
+        int tid_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_));
+        const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int q = tid & 3, base = lane & ~3;
+        // ---- F1: rank sort (keys are unique: "keys greater than mine" is a permutation), as the rank sort of the other path ----
+        const int n8 = (n_stored + 7) & ~7;
+        int *s_rankacc = reinterpret_cast<int *>(ssup);
+        for (int i = n_stored + tid; i < n8; i += blockDim.x) skeys[i] = 0ull;
+        for (int i = tid; i < n_stored; i += blockDim.x) s_rankacc[i] = 0;
+        if (tid < kLazyW) s_keptw[tid] = 0ull;
+        __syncthreads();
+        if (n_stored > 0) {
+            const int P = min(16, (int)blockDim.x / n_stored);
+            const int per = ((n8 / 8 + P - 1) / P) * 8;
+            const int p = tid / n_stored, i = tid - p * n_stored;
+            const int j_lo = p * per, j_hi = min(j_lo + per, n8);
+            if (p < P && j_lo < j_hi) {
+                const unsigned long long mine = skeys[i];
+                int rank = 0;
+#pragma unroll 2
+                for (int j = j_lo; j < j_hi; j += 8) {
+                    const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(&skeys[j]);
+                    const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 2]);
+                    const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 4]);
+                    const ulonglong2 k3 = *reinterpret_cast<const ulonglong2 *>(&skeys[j + 6]);
+                    rank += (k0.x > mine) + (k0.y > mine) + (k1.x > mine) + (k1.y > mine) + (k2.x > mine) + (k2.y > mine) +
+                            (k3.x > mine) + (k3.y > mine);
+                }
+                if (P == 1) s_rankacc[i] = rank; else atomicAdd(&s_rankacc[i], rank);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n_stored; i += blockDim.x) srank[s_rankacc[i]] = skeys[i];
+        __syncthreads();
+        sorted = srank;
+        IRMV_STAMP(9);
+        // ---- F2: boxes (exactly decode_keys' arithmetic), classes and keypoints of the candidates IN SCORE ORDER: quad r / 4
+        // decodes the candidate at sorted position r.  Both rounds' logits are requested before either is used ----
+        n = n_stored < a.pre_nms_cap ? n_stored : a.pre_nms_cap;
+        {
+            f32x4 v[2][4];
+            float kq0[2], kq1[2];
+            uint32_t id_[2];
+            int an_[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int r = u * 256 + (tid >> 2);
+                const bool live = r < n_stored;                    // quad-uniform
+                const unsigned long long key = live ? srank[r] : 0ull;
+                id_[u] = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
+                an_[u] = live ? anchor_of(id_[u], a.nc, a.A) : 0;
+                int ix, iy, st, lbase, lhw, rin;
+                anchor_geom(an_[u], a.net, ix, iy, st, lbase, lhw, rin);
+                const float *rec = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin);
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[u][i] = reinterpret_cast<const f32x4 *>(rec + 16 * q)[i];
+                kq0[u] = a.nk >= 8 ? rec[kKptOff + 2 * q] : 0.f;
+                kq1[u] = a.nk >= 8 ? rec[kKptOff + 2 * q + 1] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (u * 256 >= n_stored) break;                    // workgroup-uniform
+                const int r = u * 256 + (tid >> 2);
+                float l[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { l[4 * i] = v[u][i][0]; l[4 * i + 1] = v[u][i][1]; l[4 * i + 2] = v[u][i][2]; l[4 * i + 3] = v[u][i][3]; }
+                const float d = dfl_side(l);
+                const float dl = __shfl(d, base), dt = __shfl(d, base + 1), dr = __shfl(d, base + 2), db = __shfl(d, base + 3);
+                if (r < n_stored) {
+                    if (q == 0) {
+                        int ix, iy, st, lbase, lhw, rin;
+                        anchor_geom(an_[u], a.net, ix, iy, st, lbase, lhw, rin);
+                        const float ax = (float)ix + 0.5f, ay = (float)iy + 0.5f, sf = (float)st;
+                        f32x4 box;
+                        box[0] = (ax - dl) * sf;
+                        box[1] = (ay - dt) * sf;
+                        box[2] = (ax + dr) * sf;
+                        box[3] = (ay + db) * sf;
+                        cbox[r] = box;
+                        ccls[r] = r < n ? (int)(id_[u] % (uint32_t)a.nc) : -1;   // (behind pre_nms_cap: not walked)
+                    }
+                    ckpt[8 * r + 2 * q] = kq0[u];
+                    ckpt[8 * r + 2 * q + 1] = kq1[u];
+                }
+            }
+        }
+        for (int i = n_stored + tid; i < ((n_stored + 63) & ~63); i += blockDim.x) ccls[i] = -1;   // padding up to the block boundary: no class
+        __syncthreads();
+        IRMV_STAMP(1);
+        // ---- F4: class-major order.  Per class and 64-candidate word of the score order: who has that class ----
+        const int nw = (n_stored + 63) >> 6;
+        if (wave < nw) {
+            const int c = ccls[tid];
+            for (int k = 0; k < a.nc; k++) {
+                const unsigned long long mk = __ballot(c == k);
+                if (lane == 0) s_clsmask[k][wave] = mk;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {           // class sizes -> class-major base offsets, and the widest class in 64-bit words
+            int cnt = 0;
+            if (lane < a.nc)
+                for (int w = 0; w < nw; w++) cnt += __popcll(s_clsmask[lane][w]);
+            int inc = cnt, mx = cnt;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const int t = __shfl_up(inc, o), m2 = __shfl_xor(mx, o);
+                if (lane >= o) inc += t;
+                mx = mx > m2 ? mx : m2;
+            }
+            if (lane < 16) { s_cbase[lane] = inc - cnt; s_ccnt[lane] = cnt; }
+            if (lane == 0) s_W = (mx + 63) >> 6;
+        }
+        __syncthreads();
+        if (tid < (nw << 6)) {
+            const int i = tid, c = ccls[i];
+            if (c >= 0) {
+                int r = __popcll(s_clsmask[c][wave] & ((1ull << lane) - 1ull));
+                for (int w = 0; w < wave; w++) r += __popcll(s_clsmask[c][w]);
+                const int k = s_cbase[c] + r;
+                const f32x4 box = cbox[i];
+                mbox[k] = box;
+                marea[k] = (box[2] - box[0]) * (box[3] - box[1]);
+                minfo[k] = (i << 8) | c;
+            }
+        }
+        __syncthreads();
+        IRMV_STAMP(10);
+        // ---- F5: suppression rows in CLASS-LOCAL coordinates: bit jj of word w of row k <=> member 64 w + jj of k's class
+        // (earlier than k in score order) has IoU > thr with k.  An item is a quarter word (16 members); the quarter index is the
+        // slowest-running one, so that whole waves fall idle where classes are shorter than the widest ----
+        {
+            const int W = s_W;
+            unsigned short *rows16 = reinterpret_cast<unsigned short *>(ssup);
+            for (int item = tid; item < 4 * W * n; item += blockDim.x) {
+                const int rest = item / n, k = item - rest * n;
+                const int q4 = rest / W, w = rest - q4 * W;
+                const int c = minfo[k] & 255, cb = s_cbase[c], r = k - cb;
+                const int j0 = (w << 6) + (q4 << 4);
+                unsigned int mask = 0u;
+                if (j0 < r) {
+                    const f32x4 bi = mbox[k];
+                    const float ai = marea[k];
+                    const int jend = r - j0 < 16 ? r - j0 : 16;
+                    // all sixteen tests, predicated, in two batches of eight whose LDS reads are issued together: a loop to jend
+                    // paid the LDS latency and the test's dependent chain once per member (~ 300 cycles each).  (Members behind
+                    // jend: other rows of the list, or stale slots behind it inside the 512-slot arrays -- read, never used.)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        if (8 * h >= jend) break;
+                        f32x4 bj[8];
+                        float aj[8];
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) {
+                            const int m = min(cb + j0 + 8 * h + jj, kRankSortUse - 1);
+                            bj[jj] = mbox[m];
+                            aj[jj] = marea[m];
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++)
+                            if (8 * h + jj < jend && iou_gt_area(bj[jj], aj[jj], bi, ai, a.iou_thr)) mask |= 1u << (8 * h + jj);
+                    }
+                }
+                rows16[((k * kMatW_ + w) << 2) + q4] = (unsigned short)mask;
+            }
+        }
+        __syncthreads();
+        IRMV_STAMP(2);
+        // ---- F6: wave c walks class c, 64 members per step (the in-order resolve of the matrix path below) ----
+        if (wave < a.nc) {
+            const int cnt = s_ccnt[wave], cb = s_cbase[wave];
+            unsigned long long *ck = s_clsmask[wave];          // from here on: the class's survivors, class-local positions
+            for (int blk = 0; blk < ((cnt + 63) >> 6); blk++) {
+                const int il = (blk << 6) + lane, k = cb + il;
+                const bool valid = il < cnt;
+                bool alive = valid;
+                for (int w = 0; w < blk; w++)
+                    if (valid && (ssup[k * kMatW_ + w] & ck[w]) != 0ull) alive = false;
+                const unsigned long long sup = valid ? ssup[k * kMatW_ + blk] : 0ull;
+                unsigned long long U = __ballot(alive), K = 0ull;   // undecided, kept
+                while (U) {
+                    const bool ready = ((U >> lane) & 1ull) && (sup & U) == 0ull;
+                    const unsigned long long R = __ballot(ready);
+                    K |= __ballot(ready && (sup & K) == 0ull);
+                    U &= ~R;
+                }
+                if (lane == 0) ck[blk] = K;
+                if ((K >> lane) & 1ull) {
+                    const int i = minfo[k] >> 8;                 // flag the survivor at its score-order position
+                    atomicOr(reinterpret_cast<unsigned int *>(s_keptw) + (i >> 5), 1u << (i & 31));
+                }
+                wave_lds_sync();
+            }
+        }
+        __syncthreads();
+        // ---- F7: the first max_det survivors in score order ----
+        if (tid < (nw << 6)) {
+            const unsigned long long word = s_keptw[wave];
+            if ((word >> lane) & 1ull) {
+                int pos = __popcll(word & ((1ull << lane) - 1ull));
+                for (int w = 0; w < wave; w++) pos += __popcll(s_keptw[w]);
+                if (pos < a.max_det) {
+                    kept_box[pos] = cbox[tid];
+                    kept_cls[pos] = ccls[tid];
+                    kept_key[pos] = srank[tid];
+                    kept_src[pos] = (unsigned short)tid;
+                }
+            }
+        }
+        if (tid == 0) {
+            int total = 0;
+            for (int w = 0; w < nw; w++) total += __popcll(s_keptw[w]);
+            s_kept = total < a.max_det ? total : a.max_det;
+        }
+    }
+    } else {
     if (a.keys_only) {
         decode_keys(skeys, n_stored);
         __syncthreads();                                // boxes visible to the whole workgroup
@@ -677,10 +937,8 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     const f32x4 *boxes = reinterpret_cast<const f32x4 *>(a.boxes) + (size_t)b * a.A;
     IRMV_STAMP(1);
 
-    constexpr int kMatN = 512, kMatW = kMatN / 64;   // up to this many candidates the FULL suppression matrix fits ssup
-    constexpr int kLazyN = kLazyN_, kLazyW = kLazyN / 64;   // up to this many: the matrix one 64-candidate block of rows at a time
-    __shared__ unsigned long long s_keptw[kLazyW];        // per 64-candidate block: its survivors
-    __shared__ unsigned long long s_clsmask[16][kLazyW];  // per class and block: which candidates have that class
+    constexpr int kMatN = 512, kMatW = kMatW_;   // up to this many candidates the FULL suppression matrix fits ssup
+    constexpr int kLazyN = kLazyN_;   // up to this many: the matrix one 64-candidate block of rows at a time
     if (n <= kMatN) {
         // ---- 2'. full suppression matrix ----
         // Every IoU test the greedy walk can need, evaluated up front by the whole workgroup; the walk itself is then
@@ -937,6 +1195,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
         if (lane == 0) s_kept = kept;
     }
     }
+    }
     __syncthreads();
     // attempt 0 stands if it filled max_det or walked everything the full algorithm would walk
     if (!truncated || s_kept >= a.max_det || n >= n_full) break;
@@ -957,6 +1216,27 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
     DevDet *sdet = reinterpret_cast<DevDet *>(skeys);   // (the key list is dead: the survivors' keys sit in kept_key)
     const int j = tid >> 1;
     {
+        // keypoint logits: from LDS where the class-walk path has put them, else from the head record.  (Read BEFORE the
+        // staging is written: with max_det > 236 the records reach into the keypoints' part of the key list.)
+        float kpv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int an = 0;
+        if (j < kept) {
+            const uint32_t id = 0xffffffffu - (uint32_t)(kept_key[j] & 0xffffffffu);
+            an = anchor_of(id, a.nc, a.A);
+            if (kp_lds) {
+                const f32x4 *kl = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(skeys + kKptLds) + 8 * cls_list[0][j]);
+                const f32x4 k0 = kl[0], k1 = kl[1];
+                kpv[0] = k0[0]; kpv[1] = k0[1]; kpv[2] = k0[2]; kpv[3] = k0[3];
+                kpv[4] = k1[0]; kpv[5] = k1[1]; kpv[6] = k1[2]; kpv[7] = k1[3];
+            } else {
+                int ix, iy, s, lbase, lhw, rin;
+                anchor_geom(an, a.net, ix, iy, s, lbase, lhw, rin);
+                const float *kp = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin) + kKptOff;
+#pragma unroll
+                for (int q = 0; q < 8; q++) kpv[q] = q < a.nk ? kp[q] : 0.f;
+            }
+        }
+        __syncthreads();
         if (j < kept) {           // pair-uniform
             // the record's fields go to the LDS staging as they are produced (lane 0 of the pair): held in registers across the
             // solver they spilled
@@ -964,16 +1244,10 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             const bool w = (tid & 1) == 0;
             const f32x4 box = kept_box[j];
             const unsigned long long key = kept_key[j];
-            const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
-            const int an = anchor_of(id, a.nc, a.A);
             const float logit = unorderable((uint32_t)(key >> 32));
             int ix, iy, s, lbase, lhw, rin;
             anchor_geom(an, a.net, ix, iy, s, lbase, lhw, rin);
             const float axm = ((float)ix + 0.5f) - 0.5f, aym = ((float)iy + 0.5f) - 0.5f, sf = (float)s;
-            const float *kp = head_rec(a.head_all, a.slots_total, a.first + b, lbase, lhw, rin) + kKptOff;
-            float kpv[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) kpv[q] = q < a.nk ? kp[q] : 0.f;
             if (w) {
                 d->score = 1.0f / (1.0f + irmv_expf(-logit));
                 d->cls = kept_cls[j];

@@ -210,6 +210,66 @@ def test_post_ties_and_identical_boxes(eng):
     assert list(raw["anchors"][:2]) == [50, 100] and raw["classes"][1] == 2
 
 
+def _class_walk_heads():
+    """Heads of up to 512 candidates (and three above, for the first walk on the head of the list) that lean on every part of
+    nms_pnp_kernel's class-major path: the widest class in one to eight 64-bit words, chains of suppression inside a class,
+    equal scores, several classes on one anchor, classes without candidates."""
+    out = {}
+    rng = np.random.default_rng(404)
+    out["fourteen classes, ~ 400"] = _synthetic_head(rng, 0.0034)
+    out["fourteen classes, ~ 120"] = _synthetic_head(rng, 0.001)
+    one = np.zeros((8400, 86), np.float32)                   # ONE class, 500 candidates on neighbouring stride-8 anchors: wide,
+    one[:, 64:78] = -20.0                                    # heavily overlapping boxes -> rows of eight words, long chains
+    one[:, :64] = 0.05 * rng.standard_normal((8400, 64))
+    one[:, 78:] = 0.25 + 0.3 * rng.standard_normal((8400, 8))
+    one[:500, 64 + 6] = 1.0 + rng.permutation(500).astype(np.float32) * 2e-3
+    out["one class, 500 overlapping"] = one
+    two = one.copy()                                         # two interleaved classes of 250 (130 + 120 words apart) + singletons
+    two[:, 64:78] = -20.0
+    two[0:500:2, 64 + 1] = 1.0 + rng.permutation(250).astype(np.float32) * 2e-3
+    two[1:500:2, 64 + 12] = 1.0 + rng.permutation(250).astype(np.float32) * 2e-3
+    two[6000:6010, 64 + 13] = 2.0
+    two[8399, 64 + 0] = 0.5
+    out["two classes interleaved + equal scores"] = two
+    ties = one.copy()                                        # every candidate the SAME logit: order = anchor, then class
+    ties[:, 64:78] = -20.0
+    ties[:300, 64 + 4] = 1.25
+    ties[100:200, 64 + 9] = 1.25                             # ... and a second class on a hundred of those anchors
+    out["all scores equal, two classes per anchor"] = ties
+    lone = one.copy()
+    lone[:, 64:78] = -20.0
+    lone[4242, 64 + 7] = 3.0
+    out["one candidate"] = lone
+    out["cluster of 700 in front (first walk starts over)"] = _clustered_head(rng, 700, 500)
+    out["cluster of 400 in front of 800"] = _clustered_head(rng, 400, 800)
+    return out
+
+
+@pytest.mark.parametrize("cap,md", [(4096, 100), (150, 100), (4096, 7), (2048, 256)])
+def test_class_walk_path_on_crafted_heads(blob, monkeypatch, cap, md):
+    """run_post takes its candidates from scan_decode_kernel, which also decodes their boxes -- nms_pnp_kernel then skips its
+    class-major path (the one every whole step takes: sort, decode in score order into LDS, per-class rows and walks, cap in
+    score order).  IRMV_POST_KEYS_ONLY=1 makes run_post's NMS decode its own boxes as a whole step's does, so the crafted heads
+    reach that path: each against the oracle, bit for bit, at four (pre_nms_cap, max_det) pairs -- a cap below the candidate
+    count, a max_det the first class fills, the largest max_det (records reach into the keypoints' LDS) -- and against the
+    round-3 walk (IRMV_NMS_CLASSWALK=0)."""
+    monkeypatch.setenv("IRMV_POST_KEYS_ONLY", "1")
+    got = {}
+    for cw in ("1", "0"):
+        monkeypatch.setenv("IRMV_NMS_CLASSWALK", cw)
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, pre_nms_cap=cap, max_det=md) as e:
+            for name, head in _class_walk_heads().items():
+                raw = _assert_post_exact(e, head, max_det=md, pre_nms_cap=cap)
+                got[(cw, name)] = _raw_tuple(raw)
+                if name == "one class, 500 overlapping":
+                    assert raw["n_candidates"] == 500 and 1 < raw["num_dets"] < 500
+                if name == "fourteen classes, ~ 400":
+                    assert 300 < raw["n_candidates"] <= 512
+    for name in _class_walk_heads():
+        a, b = got[("1", name)], got[("0", name)]
+        assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:])), name
+
+
 def test_post_max_det_and_thresholds(blob):
     rng = np.random.default_rng(11)
     head = _synthetic_head(rng, 0.01)
@@ -531,7 +591,7 @@ def test_resident_weight_kernels_are_bitwise_the_chunked_ones(blob, monkeypatch,
 @pytest.mark.parametrize("switch", ["IRMV_INLINE_COPIES=1", "IRMV_ZERO_COPY_RESULTS=0", "IRMV_SPLIT_SCAN=0", "IRMV_EMIT_SCAN=0",
                                     "IRMV_FUSED_HEAD=0", "IRMV_MERGE_HEAD0=0", "IRMV_GROUP_HEAD=0", "IRMV_NO_PF2=1", "IRMV_NO_DEEP=1",
                                     "IRMV_FRONT_FASTX=0", "IRMV_FRONT_DIRECT=0", "IRMV_FRONT_TILE8=0",
-                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1"])
+                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1", "IRMV_NMS_CLASSWALK=0"])
 def test_every_remaining_switch_is_bitwise_the_default(blob, monkeypatch, switch):
     """The environment switches that select between implementations of the same arithmetic (where the copies ride, where the
     results land, where candidates are found, which launches are merged): heads and detections of a batched step, of
