@@ -1689,10 +1689,27 @@ bool launch_conv_lds_multi(int nt, const ConvArgs *a, const half_t *const *wl, i
 // pass 2 takes the vertical maxima of those: 13 + 27 LDS reads per (pixel, 8
 // channels) instead of 169 global loads.  Max is exact, so this is bit-identical
 // to the chained pools.
+// (round 4: the maxima are v_pk_max_f16 on the eight halves of an item -- four instructions; the compare-and-select the
+// compiler makes of `v > m ? v : m` on fp16 vectors was ~ 16, and with it the kernel issued 29 vector instructions per
+// LDS read.  Inline asm: the builtin max canonicalises both operands first, three instructions instead of one.  Activations
+// are never NaN; of two zeros of different sign either may come out, which no later layer can tell apart.)
+__device__ __forceinline__ half8 hmax8(half8 a, half8 b)
+{
+    u32x4_t x = __builtin_bit_cast(u32x4_t, a);
+    const u32x4_t y = __builtin_bit_cast(u32x4_t, b);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        unsigned int r;
+        asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(x[i]), "v"(y[i]));
+        x[i] = r;
+    }
+    return __builtin_bit_cast(half8, x);
+}
+
 __global__ __launch_bounds__(512) void sppf_pool_lds_kernel(half_t *buf, int H, int W, int C, int CW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int HW = H * W, chunks = CW >> 3;
+    const int HW = H * W, chunks = CW >> 3, cs = chunks == 1 ? 0 : (chunks == 2 ? 1 : 2);   // (slabs are 8, 16 or 32 channels wide)
     half8 *sa = reinterpret_cast<half8 *>(smem);          // [HW][chunks]
     half8 *s2 = sa + (size_t)HW * chunks;                 // horizontal max, radius 2
     half8 *s4 = s2 + (size_t)HW * chunks;
@@ -1703,71 +1720,59 @@ __global__ __launch_bounds__(512) void sppf_pool_lds_kernel(half_t *buf, int H, 
     half_t *base = buf + (size_t)b * HW * ld + slab * CW;
     const int items = HW * chunks;
     for (int t = threadIdx.x; t < items; t += blockDim.x) {
-        const int p = t / chunks, ch = t - p * chunks;
+        const int p = t >> cs, ch = t & (chunks - 1);
         sa[t] = *reinterpret_cast<const half8 *>(base + (size_t)p * ld + ch * 8);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < items; t += blockDim.x) {
-        const int p = t / chunks, ch = t - p * chunks;
+        const int p = t >> cs, ch = t & (chunks - 1);
         const int y = p / W, x = p - y * W;
-        half8 m2 = sa[t], m4, m6;
+        // all twelve neighbours requested at once (an index clamped into the row reads a pixel that is in the window anyway,
+        // or the pixel itself: max is idempotent), then three nested maxima
+        half8 v[13];
 #pragma unroll
-        for (int d = 1; d <= 2; d++) {
-            if (x - d >= 0) { const half8 v = sa[(p - d) * chunks + ch];
-#pragma unroll
-                for (int i = 0; i < 8; i++) m2[i] = v[i] > m2[i] ? v[i] : m2[i]; }
-            if (x + d < W) { const half8 v = sa[(p + d) * chunks + ch];
-#pragma unroll
-                for (int i = 0; i < 8; i++) m2[i] = v[i] > m2[i] ? v[i] : m2[i]; }
+        for (int d = -6; d <= 6; d++) {
+            int xx = x + d;
+            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            v[d + 6] = sa[(y * W + xx) * chunks + ch];
         }
-        m4 = m2;
-#pragma unroll
-        for (int d = 3; d <= 4; d++) {
-            if (x - d >= 0) { const half8 v = sa[(p - d) * chunks + ch];
-#pragma unroll
-                for (int i = 0; i < 8; i++) m4[i] = v[i] > m4[i] ? v[i] : m4[i]; }
-            if (x + d < W) { const half8 v = sa[(p + d) * chunks + ch];
-#pragma unroll
-                for (int i = 0; i < 8; i++) m4[i] = v[i] > m4[i] ? v[i] : m4[i]; }
-        }
-        m6 = m4;
-#pragma unroll
-        for (int d = 5; d <= 6; d++) {
-            if (x - d >= 0) { const half8 v = sa[(p - d) * chunks + ch];
-#pragma unroll
-                for (int i = 0; i < 8; i++) m6[i] = v[i] > m6[i] ? v[i] : m6[i]; }
-            if (x + d < W) { const half8 v = sa[(p + d) * chunks + ch];
-#pragma unroll
-                for (int i = 0; i < 8; i++) m6[i] = v[i] > m6[i] ? v[i] : m6[i]; }
-        }
+        half8 m2 = hmax8(hmax8(hmax8(v[4], v[5]), hmax8(v[7], v[8])), v[6]);
+        half8 m4 = hmax8(hmax8(hmax8(v[2], v[3]), hmax8(v[9], v[10])), m2);
+        half8 m6 = hmax8(hmax8(hmax8(v[0], v[1]), hmax8(v[11], v[12])), m4);
         s2[t] = m2; s4[t] = m4; s6[t] = m6;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < items; t += blockDim.x) {
-        const int p = t / chunks, ch = t - p * chunks;
-        const int y = p / W;
-        half8 m5 = s2[t], m9 = s4[t], m13 = s6[t];
-        for (int d = 1; d <= 6; d++) {
+    // vertical maxima, TWO vertically adjacent pixels per item: their windows share 12 / 8 / 4 of the 13 / 9 / 5 rows
+    // (14 + 10 + 6 = 30 LDS reads for two pixels instead of 54)
+    const int HP = (H + 1) >> 1, items2 = HP * W * chunks;
+    for (int t = threadIdx.x; t < items2; t += blockDim.x) {
+        const int pp = t >> cs, ch = t & (chunks - 1);
+        const int yp = pp / W, x = pp - yp * W, y0 = 2 * yp;
+        auto row = [&](int yy) { return ((yy < 0 ? 0 : (yy >= H ? H - 1 : yy)) * W + x) * chunks + ch; };
+        half8 r6[14], r4[10], r2[6];
 #pragma unroll
-            for (int sgn = -1; sgn <= 1; sgn += 2) {
-                const int yy = y + sgn * d;
-                if (yy < 0 || yy >= H) continue;
-                const int q = (p + sgn * d * W) * chunks + ch;
-                const half8 v6 = s6[q];
+        for (int i = 0; i < 14; i++) r6[i] = s6[row(y0 - 6 + i)];
 #pragma unroll
-                for (int i = 0; i < 8; i++) m13[i] = v6[i] > m13[i] ? v6[i] : m13[i];
-                if (d <= 4) { const half8 v4 = s4[q];
+        for (int i = 0; i < 10; i++) r4[i] = s4[row(y0 - 4 + i)];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) m9[i] = v4[i] > m9[i] ? v4[i] : m9[i]; }
-                if (d <= 2) { const half8 v2 = s2[q];
+        for (int i = 0; i < 6; i++) r2[i] = s2[row(y0 - 2 + i)];
+        // shared middles first, then the row only one of the two windows holds
+        half8 c6 = r6[1], c4 = r4[1], c2 = r2[1];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) m5[i] = v2[i] > m5[i] ? v2[i] : m5[i]; }
-            }
+        for (int i = 2; i < 13; i++) c6 = hmax8(c6, r6[i]);
+#pragma unroll
+        for (int i = 2; i < 9; i++) c4 = hmax8(c4, r4[i]);
+#pragma unroll
+        for (int i = 2; i < 5; i++) c2 = hmax8(c2, r2[i]);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int y = y0 + k;
+            if (y >= H) break;
+            half_t *o = base + (size_t)(y * W + x) * ld + ch * 8;
+            *reinterpret_cast<half8 *>(o + C) = hmax8(c2, k ? r2[5] : r2[0]);
+            *reinterpret_cast<half8 *>(o + 2 * C) = hmax8(c4, k ? r4[9] : r4[0]);
+            *reinterpret_cast<half8 *>(o + 3 * C) = hmax8(c6, k ? r6[13] : r6[0]);
         }
-        half_t *o = base + (size_t)p * ld + ch * 8;
-        *reinterpret_cast<half8 *>(o + C) = m5;
-        *reinterpret_cast<half8 *>(o + 2 * C) = m9;
-        *reinterpret_cast<half8 *>(o + 3 * C) = m13;
     }
 }
 
