@@ -1277,7 +1277,7 @@ static void tune_cache_load()
     int mt, nt, lds, ipw;
     while (f >> key >> mt >> nt >> lds >> ipw) {
         ConvCfg c{};
-        c.mt = mt; c.nt = nt; c.lds = (lds & 1) != 0; c.deep = (lds & 2) != 0; c.ct = (lds & 4) != 0; c.pw = (lds & 8) != 0; c.pf2 = (lds & 16) != 0; c.cm = (lds & 64) ? 2 : ((lds & 128) ? 4 : 0); c.w8 = (lds & 256) != 0; c.wr = (lds & 512) != 0; c.pp = (lds & 1024) != 0; c.ipw = ipw;   // bit 0 LDS family, 1 deep prefetch, 2 direct kernel in the LDS family's K order, 3 pointwise kernel, 4 two-step staging, 6 / 7 LDS family chunk-major over 2 / 4 images, 8 LDS family 8-wave workgroup, 9 LDS family with resident weights (ipw = images per workgroup, any value), 10 its ping-pong form
+        c.mt = mt; c.nt = nt; c.lds = (lds & 1) != 0; c.deep = (lds & 2) != 0; c.ct = (lds & 4) != 0; c.pw = (lds & 8) != 0; c.pf2 = (lds & 16) != 0; c.pf4 = (lds & 32) != 0; c.cm = (lds & 64) ? 2 : ((lds & 128) ? 4 : 0); c.w8 = (lds & 256) != 0; c.wr = (lds & 512) != 0; c.pp = (lds & 1024) != 0; c.ipw = ipw;   // bit 0 LDS family, 1 deep prefetch, 2 direct kernel in the LDS family's K order, 3 pointwise kernel, 4 two-step staging, 5 four-step staging, 6 / 7 LDS family chunk-major over 2 / 4 images, 8 LDS family 8-wave workgroup, 9 LDS family with resident weights (ipw = images per workgroup, any value), 10 its ping-pong form
         g_tune_cache[key] = c;
     }
 }
@@ -1289,7 +1289,7 @@ static void tune_cache_save()
     std::lock_guard<std::mutex> lk(g_tune_mu);
     std::ofstream f(path);
     for (auto &kv : g_tune_cache)
-        f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0) | (kv.second.pw ? 8 : 0) | (kv.second.pf2 ? 16 : 0) | (kv.second.cm == 2 ? 64 : 0) | (kv.second.cm == 4 ? 128 : 0) | (kv.second.w8 ? 256 : 0) | (kv.second.wr ? 512 : 0) | (kv.second.pp ? 1024 : 0)) << ' ' << kv.second.ipw << '\n';
+        f << kv.first << ' ' << kv.second.mt << ' ' << kv.second.nt << ' ' << ((kv.second.lds ? 1 : 0) | (kv.second.deep ? 2 : 0) | (kv.second.ct ? 4 : 0) | (kv.second.pw ? 8 : 0) | (kv.second.pf2 ? 16 : 0) | (kv.second.pf4 ? 32 : 0) | (kv.second.cm == 2 ? 64 : 0) | (kv.second.cm == 4 ? 128 : 0) | (kv.second.w8 ? 256 : 0) | (kv.second.wr ? 512 : 0) | (kv.second.pp ? 1024 : 0)) << ' ' << kv.second.ipw << '\n';
 }
 
 static int lds_index(int nt) { return nt == 8 ? 3 : (nt == 4 ? 2 : (nt == 2 ? 1 : 0)); }
@@ -1299,7 +1299,7 @@ static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int coun
     const int li = lds_index(c.nt);
     if (c.pw) return launch_conv_pw(c, a, s);
     if (c.wr) return c.lds && op.w_lds[2] && launch_conv_wres(c.ipw, a, op.w_lds[2], count, s, c.pp);
-    if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s, c.pf2, c.cm, c.w8);
+    if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s, c.pf4 ? 2 : (c.pf2 ? 1 : 0), c.cm, c.w8);
     if (c.ct) {   // direct kernel in the LDS family's K order, on that family's nt = 1 weight packing
         if (!op.w_lds[0] || a.n2 > 0) return false;
         ConvArgs a2 = a;
@@ -1313,8 +1313,8 @@ static void cfg_name(const ConvCfg &c, char *buf, int n)
 {
     if (c.pw) snprintf(buf, n, c.ipw > 1 ? "conv1x1s1_pw_n%d" : "conv1x1s1_pw", c.ipw);
     else if (c.wr) snprintf(buf, n, "conv3x3s1_wres%s_i%d", c.pp ? "_pp" : "", c.ipw);
-    else if (c.lds && c.ipw > 1) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d_i%d%s%s", c.stride, c.mt, c.nt, c.ipw, c.cm ? "_cm" : (c.pf2 ? "_p2" : ""), c.w8 ? "_w8" : "");
-    else if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d%s%s", c.stride, c.mt, c.nt, c.pf2 ? "_p2" : "", c.w8 ? "_w8" : "");
+    else if (c.lds && c.ipw > 1) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d_i%d%s%s", c.stride, c.mt, c.nt, c.ipw, c.cm ? "_cm" : (c.pf4 ? "_p4" : (c.pf2 ? "_p2" : "")), c.w8 ? "_w8" : "");
+    else if (c.lds) snprintf(buf, n, "conv3x3s%d_lds_mt%d_nt%d%s%s", c.stride, c.mt, c.nt, c.pf4 ? "_p4" : (c.pf2 ? "_p2" : ""), c.w8 ? "_w8" : "");
     else conv_cfg_name(c, buf, n);
 }
 
@@ -1398,6 +1398,7 @@ static int autotune_convs(irmv_engine *e)
                     if (ok && h.deep) ok = (h.mt == 1 || (h.mt == 2 && h.nt == 1)) && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1;
                     if (ok && h.ct) ok = op.w_lds[0] != nullptr;
                     if (ok && h.pf2) ok = h.lds && h.mt == 1 && !want_fuse;
+                    if (ok && h.pf4) ok = !getenv("IRMV_NO_PF4") && h.lds && !h.pf2 && !h.cm && !h.w8 && !h.wr && h.mt == 1 && h.nt == 1 && !want_fuse;
                     if (ok && h.cm && h.nt != 8) ok = !getenv("IRMV_NO_CM") && h.lds && !h.pf2 && h.cm == h.ipw && h.nt == 4 && ((h.mt == 1 && (!want_fuse || h.cm == 4)) || (h.mt == 2 && h.cm == 2));
                     if (ok && h.w8 && h.nt == 4) ok = !getenv("IRMV_NO_W8") && h.lds && op.cfg.stride == 2 && !want_fuse && !h.pf2 && (h.mt == 1 || h.mt == 2) &&
                                                      (h.cm == 0 || (h.cm == h.ipw && ((h.mt == 2 && h.cm == 2) || (h.mt == 1 && h.cm == 4))));
@@ -1406,11 +1407,12 @@ static int autotune_convs(irmv_engine *e)
                     if (ok && h.w8 && h.nt != 4 && h.nt != 8) ok = false;
                     if (ok && h.cm && h.nt == 8 && !h.w8) ok = false;
                     if (ok && !h.w8 && getenv("IRMV_FORCE_W8") && lds_ok && op.cfg.stride == 2) ok = false;
+                    if (ok && !h.pf4 && getenv("IRMV_FORCE_PF4") && lds_ok && op.cin >= 128 && !want_fuse) ok = false;   // parity tests: re-tune so that the forced tile is tried
                     if (ok && h.nt != 8 && getenv("IRMV_FORCE_NT8") && lds_ok && op.cfg.stride == 2 && op.w_lds[3] && !want_fuse) ok = false;   // parity tests: the 128-channel workgroup wherever it exists
                     if (ok && !h.cm && getenv("IRMV_FORCE_CM") && lds_ok && counts[pass] >= 2) ok = false;   // parity tests: the chunk-major tiles wherever one exists
                     if (ok) {
                         best_cfg = op.cfg;
-                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct; best_cfg.pw = h.pw; best_cfg.pf2 = h.pf2; best_cfg.cm = h.cm; best_cfg.w8 = h.w8; best_cfg.wr = h.wr; best_cfg.pp = h.pp;
+                        best_cfg.mt = h.mt; best_cfg.nt = h.nt; best_cfg.lds = h.lds; best_cfg.ipw = h.ipw; best_cfg.deep = h.deep; best_cfg.ct = h.ct; best_cfg.pw = h.pw; best_cfg.pf2 = h.pf2; best_cfg.pf4 = h.pf4; best_cfg.cm = h.cm; best_cfg.w8 = h.w8; best_cfg.wr = h.wr; best_cfg.pp = h.pp;
                         best = 0.f;
                         have_hit = true;
                     } else if (getenv("IRMV_AUTOTUNE_VERBOSE") || getenv("IRMV_TUNE_WARN"))
@@ -1454,7 +1456,7 @@ static int autotune_convs(irmv_engine *e)
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             if (want_fuse && nt != 4) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                             TRY(time_cfg(c));
                         }
                 // LDS family, smallest pixel tile, staging two steps ahead (layers whose step is shorter than a memory round trip)
@@ -1463,16 +1465,24 @@ static int autotune_convs(irmv_engine *e)
                         for (int ipw = 1; ipw <= std::min(4, counts[pass]); ipw *= 2) {
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = 1; c.nt = nt; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = true; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                            c.mt = 1; c.nt = nt; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = true; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                             TRY(time_cfg(c));
                         }
+                // ... and four steps ahead: layers of four or more chunks on maps small enough for four register sets (a lone frame's
+                // 20 x 20 layers: every step of a workgroup in flight at once)
+                if (fam == 1 && !want_fuse && !getenv("IRMV_NO_PF4") && op.cin >= 128 && op.w_lds[0]) {
+                    ConvCfg c = op.cfg;
+                    c.mt = 1; c.nt = 1; c.lds = true; c.ipw = 1; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = true; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                    TRY(time_cfg(c));
+                    if (getenv("IRMV_FORCE_PF4") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests: wherever it exists
+                }
                 // LDS family, chunk-major over the workgroup's images: a chunk's weights staged once for all of them
                 if (fam == 1 && op.cout_pad % 64 == 0 && !getenv("IRMV_NO_CM"))
                     for (int mt = 1; mt <= 2; mt *= 2)
                         for (int ipw = 2; ipw <= std::min(mt == 1 ? 4 : 2, counts[pass]); ipw *= 2) {
                             if (want_fuse && mt == 1 && ipw == 2) continue;   // (no instantiation with the fused 1x1)
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = ipw; c.w8 = false; c.wr = false; c.pp = false;
+                            c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = ipw; c.w8 = false; c.wr = false; c.pp = false;
                             TRY(time_cfg(c));
                             if (getenv("IRMV_FORCE_CM") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                         }
@@ -1484,7 +1494,7 @@ static int autotune_convs(irmv_engine *e)
                             for (int cmv = 0; cmv < 2; cmv++) {
                                 if (cmv && !((mt == 2 && ipw == 2) || (mt == 1 && ipw == 4))) continue;
                                 ConvCfg c = op.cfg;
-                                c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = cmv ? ipw : 0; c.w8 = true; c.wr = false; c.pp = false;
+                                c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = cmv ? ipw : 0; c.w8 = true; c.wr = false; c.pp = false;
                                 TRY(time_cfg(c));
                                 if (getenv("IRMV_FORCE_W8") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                             }
@@ -1496,7 +1506,7 @@ static int autotune_convs(irmv_engine *e)
                         for (int cmv = 0; cmv < 2; cmv++) {
                             if (cmv && ipw != 2) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = 1; c.nt = 8; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = cmv ? 2 : 0; c.w8 = true; c.wr = false; c.pp = false;
+                            c.mt = 1; c.nt = 8; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = cmv ? 2 : 0; c.w8 = true; c.wr = false; c.pp = false;
                             TRY(time_cfg(c));
                             if (getenv("IRMV_FORCE_NT8") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                         }
@@ -1513,7 +1523,7 @@ static int autotune_convs(irmv_engine *e)
                         for (int k = 0; k < 3; k++) {
                             if (k > 0 && (cand[k] == cand[0] || (k == 2 && cand[2] == cand[1]))) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = 2; c.nt = 4; c.lds = true; c.ipw = cand[k]; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = true; c.pp = ppv != 0;
+                            c.mt = 2; c.nt = 4; c.lds = true; c.ipw = cand[k]; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = true; c.pp = ppv != 0;
                             TRY(time_cfg(c));
                         }
                     }
@@ -1523,14 +1533,14 @@ static int autotune_convs(irmv_engine *e)
                     const int v = atoi(fw);
                     for (int ppv = v > 0 ? 1 : 0; ppv >= 0; ppv--) {
                         ConvCfg c = op.cfg;
-                        c.mt = 2; c.nt = 4; c.lds = true; c.ipw = std::max(1, std::min(counts[pass], v < 0 ? -v : v)); c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = true; c.pp = ppv != 0;
+                        c.mt = 2; c.nt = 4; c.lds = true; c.ipw = std::max(1, std::min(counts[pass], v < 0 ? -v : v)); c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = true; c.pp = ppv != 0;
                         if (conv_wres_bytes(a, op.cfg.stride, c.pp) > 0 && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; break; }
                     }
                 }
                 // 1x1 layers: the persistent pointwise kernel (same operands, same k order as the direct kernel)
                 if (conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW")) {
                     ConvCfg c = op.cfg;
-                    c.mt = 2; c.nt = 4; c.lds = false; c.ipw = 1; c.deep = false; c.ct = false; c.pw = true; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                    c.mt = 2; c.nt = 4; c.lds = false; c.ipw = 1; c.deep = false; c.ct = false; c.pw = true; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                     TRY(time_cfg(c));
                     if (getenv("IRMV_FORCE_PW") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                     // ... and its multi-block form: one workgroup runs a pixel tile against 2 / 4 output-channel blocks (input read once)
@@ -1548,7 +1558,7 @@ static int autotune_convs(irmv_engine *e)
                         for (int nt = 1; nt <= 4; nt *= 2) {
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = nt; c.lds = false; c.ipw = 1; c.deep = false; c.ct = true; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                            c.mt = mt; c.nt = nt; c.lds = false; c.ipw = 1; c.deep = false; c.ct = true; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                             TRY(time_cfg(c));
                         }
                 // single-frame steps: the latency variants of the direct kernel (deep prefetch ring), same rule.
@@ -1559,7 +1569,7 @@ static int autotune_convs(irmv_engine *e)
                     for (auto &t : tiles) {
                         if (op.cout_pad % (16 * t[1]) != 0) continue;
                         ConvCfg c = op.cfg;
-                        c.mt = t[0]; c.nt = t[1]; c.lds = false; c.ipw = 1; c.deep = true; c.ct = lds_ok; c.pw = false; c.pf2 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                        c.mt = t[0]; c.nt = t[1]; c.lds = false; c.ipw = 1; c.deep = true; c.ct = lds_ok; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
                         TRY(time_cfg(c));
                     }
                 }

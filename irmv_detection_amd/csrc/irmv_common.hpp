@@ -255,6 +255,7 @@ struct ConvCfg {
     bool ct;     // direct kernel walking K chunk-major with the LDS family's weights: bit-identical stand-in for that family
     bool pw;     // 1x1 layers: the persistent pointwise kernel (weights in LDS, pixel tiles software-pipelined)
     bool pf2;    // LDS family, mt = 1: global -> register staging two (image, chunk) steps ahead instead of one
+    bool pf4;    // LDS family, mt = 1, nt = 1: four steps ahead (a lone frame's 128-channel layers: all of a workgroup's steps in flight at once)
     bool w8;     // LDS family, stride 2: one 8-wave workgroup on a block twice as tall (weights staged for twice the pixels, mt = 2 fits LDS)
     int cm;      // LDS family: chunk-major order over the workgroup's cm = ipw images (0: image-major), weights staged once per chunk
     bool wr;     // LDS family, Cin = Cout = 64, stride 1: the layer's weights stay resident in the LDS of one 8-wave workgroup that walks ipw images
@@ -277,7 +278,7 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
 size_t conv_wres_bytes(const ConvArgs &a, int stride, bool pp);
 int conv_wres_tiles(const ConvArgs &a, int stride, bool pp);
 bool launch_conv_wres(int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pp);
-bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2 = false, int cm = 0, bool w8 = false);   // a.n2 > 0: fused 1x1 (needs stride 1, nt 4, cout 64); pf2: staging two steps ahead (mt = 1)
+bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, int pf2 = 0, int cm = 0, bool w8 = false);   // a.n2 > 0: fused 1x1 (needs stride 1, nt 4, cout 64); pf2: staging two steps ahead (mt = 1)
 
 // SPPF pooling chain: slice 0 (C ch) of [B][H][W][4C] -> slices 1..3 (5x5, 9x9, 13x13 max)
 void launch_sppf_pool(half_t *buf, int batch, int H, int W, int C, hipStream_t s);

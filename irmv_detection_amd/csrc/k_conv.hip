@@ -745,7 +745,10 @@ bool launch_conv_pw(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
 
 // 16-byte patch pieces a thread stages per chunk (registers are reserved for all of them): a stride-1 2-D block is at
 // most (16 MT + 2) x 18 pixels, the other schemes stage full-width rows or stride-2 patches.
-constexpr int lds_pmax(int stride, int mt, bool tile2d, int wr = 0) { return wr ? 4 : ((tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12); }
+constexpr int lds_pmax(int stride, int mt, bool tile2d, int wr = 0, int pf = 0)
+{   // pf = 2 (four steps staged ahead, small maps only -- lds_geom checks the fit): four register sets have to fit
+    return pf == 2 ? (stride == 1 ? 4 : 8) : (wr ? 4 : ((tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12));
+}
 
 #ifndef IRMV_ABL
 #define IRMV_ABL 0   // timing ablations of conv3x3_lds_kernel (scripts/probes/conv_probe.cpp); results are wrong with any bit set:
@@ -770,12 +773,15 @@ __device__ int g_stagger_sleeps = 0;
 #endif
 // The kernel's body as a device function of (workgroup index, grid size), so that one launch can serve several layers
 // (conv3x3_lds_multi below); conv3x3_lds_kernel itself is the thin wrapper behind it.
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, int PF = 0, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
 __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch,
                                                  int wg_x, int wg_y, int grid_x, int grid_y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    // PF: register staging of the (image, chunk) steps this many ahead of the MFMAs: 0 one step, 1 two, 2 four
+    constexpr bool PF2 = PF != 0;
+    constexpr int NPF = PF == 2 ? 4 : (PF == 1 ? 2 : 1);
     constexpr int NTH = 64 * NWV;   // NWV waves stacked along pixels (4; 8 for the stride-2 layers' large block, see launch_conv_lds)
     // PP (ping-pong, with WR): the workgroup's waves form TWO groups of NWP = NWV / 2 waves.  Each group owns a pixel tile
     // and a patch buffer of its own; they share the resident weights and run half a step apart -- while one group is in
@@ -867,7 +873,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
 
     // staging plan: element e -> (patch pixel, 16-byte quarter); weights: 9*NT*64 half8 per chunk
-    constexpr int PMAX = lds_pmax(STRIDE, MT, TILE2D, WR);   // patch 16-B pieces per thread and chunk plane (host guarantees the fit)
+    constexpr int PMAX = lds_pmax(STRIDE, MT, TILE2D, WR, PF);   // patch 16-B pieces per thread and chunk plane (host guarantees the fit)
     constexpr int WPT = (9 * NT * 64 + NTH - 1) / NTH; // weight half8 per thread
     const int n_pe = PR * PW * 4;
     const float inv_pw = 1.0f / (float)PW;
@@ -898,9 +904,12 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     // the main loop they cost 8 VGPRs per 16 output channels and pushed the N2 = 4 tiles off the large register tiles
     const half8 *w2 = s_w2 + lane;
 
-    // register staging of the (image, chunk) steps ahead of the MFMAs: one step ahead, or two (PF2: small-M layers whose
-    // step -- 9 * MT * NT MFMAs -- is shorter than a memory round trip, so a single step of lead exposes the latency)
-    half8 rp[PF2 ? 2 : 1][PMAX], rw[PF2 ? 2 : 1][WPT];
+    // register staging of the (image, chunk) steps ahead of the MFMAs: one step ahead, or two (PF = 1: small-M layers whose
+    // step -- 9 * MT * NT MFMAs -- is shorter than a memory round trip, so a single step of lead exposes the latency), or
+    // four (PF = 2, round 4: a LONE frame's 128-channel layers on the 20 x 20 maps are 14 .. 56 workgroups of four steps
+    // each -- with two steps in flight the workgroup, and with it the layer, sat out three memory round trips: 7 - 8 us
+    // where the 64-channel layers (two steps: one round trip) take 4.7)
+    half8 rp[NPF][PMAX], rw[NPF][WPT];
     const size_t img_stride = (size_t)a.Hin * a.Win * a.s0.ld;
     int l_im = 0, l_chunk = 0;   // loader position
     int c_im = 0, c_chunk = 0;   // consumer position
@@ -1408,24 +1417,24 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
             }
         }
     } else {
-        issue_loads(rp[0], rw[0]);
-        if (steps > 1) issue_loads(rp[1], rw[1]);
-        for (int s = 0; s < steps; s += 2) {
-            write_lds(rp[0], rw[0]);
-            __syncthreads();
-            if (s + 2 < steps) issue_loads(rp[0], rw[0]);   // two steps ahead
-            mma_step();
-            if (s + 1 < steps) {
-                write_lds(rp[1], rw[1]);
-                __syncthreads();
-                if (s + 3 < steps) issue_loads(rp[1], rw[1]);
-                mma_step();
+#pragma unroll
+        for (int k = 0; k < NPF; k++)
+            if (k < steps) issue_loads(rp[k], rw[k]);
+        for (int s = 0; s < steps; s += NPF) {
+#pragma unroll
+            for (int k = 0; k < NPF; k++) {
+                if (s + k < steps) {
+                    write_lds(rp[k], rw[k]);
+                    __syncthreads();
+                    if (s + k + NPF < steps) issue_loads(rp[k], rw[k]);   // NPF steps ahead
+                    mma_step();
+                }
             }
         }
     }
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, int PF = 0, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WAVES))) void conv3x3_lds_kernel(ConvArgs a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch, int nblocks, int xcd)
 {
     // 1-D grid, dealt so that every workgroup of an image group -- all its tiles, all its output-channel blocks -- runs on ONE
@@ -1436,7 +1445,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(IRMV_L
     int rem, grp;
     tile_image(blockIdx.x, wg_tiles * nblocks, groups, xcd, rem, grp);
     const int nblk = rem / wg_tiles, tile = rem - nblk * wg_tiles;
-    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, grp * wg_tiles + tile, nblk, wg_tiles * groups, nblocks);
+    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF, CM, NWV, WR, PP>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, grp * wg_tiles + tile, nblk, wg_tiles * groups, nblocks);
 }
 
 // Several independent 3x3 layers in ONE launch (the Detect branches of the three levels in a single-frame step: fifteen
@@ -1464,7 +1473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IRMV_LDS_WA
 // block tiles the image exactly (no masked lanes); otherwise the row-run scheme.  bytes == 0: not eligible.
 struct LdsGeom { bool tile2d; int tiles_x, tiles_y, twc_log2, patch_bytes; size_t bytes; };
 
-static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt, int nwv = 4, int wr = 0, bool pp = false)
+static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt, int nwv = 4, int wr = 0, bool pp = false, int pf = 0)
 {   // nwv: the waves that share one patch (ping-pong: half the workgroup's)
     LdsGeom g{false, 0, 0, 0, 0, 0};
     if (a.Cin % 32 != 0 || a.s1.C != 0 || a.s0.shift != 0) return g;
@@ -1488,7 +1497,7 @@ static LdsGeom lds_geom(const ConvArgs &a, int stride, int mt, int nt, int nwv =
         pr = (rows - 1) * stride + 3;
         pw = a.Win + 2;
     }
-    if ((size_t)pr * pw * 4 > (size_t)lds_pmax(stride, mt, g.tile2d, wr) * 64 * nwv) return g;   // staging plan: pieces per thread
+    if ((size_t)pr * pw * 4 > (size_t)lds_pmax(stride, mt, g.tile2d, wr, pf) * 64 * nwv) return g;   // staging plan: pieces per thread
     g.patch_bytes = pr * pw * pix_stride(stride);
     const int planes = wr ? wr : 1;                     // resident weights: every chunk's patch plane and weight slab at once
     const size_t bytes = (size_t)planes * (pp ? 2 : 1) * g.patch_bytes + (size_t)planes * 9 * nt * 1024 + 512 + (size_t)a.n2 * 2048;   // + bias, bias2, fused 1x1 fragments
@@ -1504,17 +1513,17 @@ size_t conv_lds_bytes(const ConvArgs &a, int stride, int mt, int nt, int *patch_
     return g.bytes;
 }
 
-template <int STRIDE, int MT, int NT, bool TILE2D, int N2, bool PF2 = false, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
+template <int STRIDE, int MT, int NT, bool TILE2D, int N2, int PF = 0, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
 static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int ipw, const LdsGeom &g, hipStream_t s)
 {
     static unsigned long long attr_done = 0;   // per instantiation: devices whose dynamic-LDS limit has been raised
     once_per_device(attr_done, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF, CM, NWV, WR, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const int groups = (batch + ipw - 1) / ipw;
     const int wg_tiles = PP ? (g.tiles_x * g.tiles_y + 1) / 2 : g.tiles_x * g.tiles_y;   // ping-pong: two tile positions per workgroup
     const int nblocks = a.cout_pad / (16 * NT);
-    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF2, CM, NWV, WR, PP>), dim3(wg_tiles * groups * nblocks), dim3(64 * NWV), g.bytes, s, a,
+    hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF, CM, NWV, WR, PP>), dim3(wg_tiles * groups * nblocks), dim3(64 * NWV), g.bytes, s, a,
                        wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch, nblocks, xcd_image_order());
 }
 
@@ -1562,7 +1571,7 @@ bool launch_conv_wres(int ipw, const ConvArgs &a, const half_t *wl, int batch, h
     return false;
 }
 
-bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, bool pf2, int cm, bool w8)
+bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, const half_t *wl, int batch, hipStream_t s, int pf2, int cm, bool w8)
 {
     if (ipw < 1) ipw = 1;
     if (w8) {   // stride-2 layers: ONE 8-wave workgroup per CU on a block of 128 mt pixels -- see DESIGN section 4
@@ -1607,12 +1616,24 @@ bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, con
 #undef IRMV_LDS_CM
         return false;
     }
-    if (pf2) {   // two-steps-ahead staging: the small pixel tiles (MT = 1), plain epilogue
+    if (pf2) {   // two- (1) or four- (2) steps-ahead staging: the small pixel tiles (MT = 1), plain epilogue
         if (mt != 1 || a.n2 > 0) return false;
+        if (pf2 == 2) {   // four register sets: one 16-channel tile, maps small enough for lds_pmax(.., pf = 2) pieces per thread
+            const LdsGeom g4 = lds_geom(a, stride, 1, nt, 4, 0, false, 2);
+            if (nt != 1 || !g4.bytes) return false;
+            if (stride == 1) {
+                if (g4.tile2d) launch_lds_inst<1, 1, 1, true, 0, 2>(a, wl, batch, ipw, g4, s);
+                else launch_lds_inst<1, 1, 1, false, 0, 2>(a, wl, batch, ipw, g4, s);
+            } else {
+                if (g4.tile2d) launch_lds_inst<2, 1, 1, true, 0, 2>(a, wl, batch, ipw, g4, s);
+                else launch_lds_inst<2, 1, 1, false, 0, 2>(a, wl, batch, ipw, g4, s);
+            }
+            return true;
+        }
 #define IRMV_LDS_P(ST_, NT_)                                                                     \
         if (stride == ST_ && nt == NT_) {                                                        \
-            if (g.tile2d) launch_lds_inst<ST_, 1, NT_, true, 0, true>(a, wl, batch, ipw, g, s);  \
-            else launch_lds_inst<ST_, 1, NT_, false, 0, true>(a, wl, batch, ipw, g, s);          \
+            if (g.tile2d) launch_lds_inst<ST_, 1, NT_, true, 0, 1>(a, wl, batch, ipw, g, s);  \
+            else launch_lds_inst<ST_, 1, NT_, false, 0, 1>(a, wl, batch, ipw, g, s);          \
             return true;                                                                         \
         }
         IRMV_LDS_P(1, 1) IRMV_LDS_P(1, 2) IRMV_LDS_P(1, 4) IRMV_LDS_P(2, 1) IRMV_LDS_P(2, 2) IRMV_LDS_P(2, 4)
@@ -1646,7 +1667,9 @@ bool launch_conv_lds(int stride, int mt, int nt, int ipw, const ConvArgs &a, con
 }
 
 bool launch_conv_lds_multi(int nt, const ConvArgs *a, const half_t *const *wl, int n, int batch, hipStream_t s)
-{
+{   // (round 4: deeper staging -- two and four steps ahead -- was built for this launch and measured on the first-stage
+    // group of a lone frame: 14.4 us one step ahead, 18.3 / 17.5 us two / four ahead at nt = 2.  The launch is 1.9 GFLOP on
+    // 500 workgroups, not a chain of round trips; removed again.)
     if (n < 1 || n > kMultiMax || !(nt == 1 || nt == 2 || nt == 4)) return false;
     LdsMultiArgs m{};
     m.n = n;

@@ -591,7 +591,7 @@ def test_resident_weight_kernels_are_bitwise_the_chunked_ones(blob, monkeypatch,
 @pytest.mark.parametrize("switch", ["IRMV_INLINE_COPIES=1", "IRMV_ZERO_COPY_RESULTS=0", "IRMV_SPLIT_SCAN=0", "IRMV_EMIT_SCAN=0",
                                     "IRMV_FUSED_HEAD=0", "IRMV_MERGE_HEAD0=0", "IRMV_GROUP_HEAD=0", "IRMV_NO_PF2=1", "IRMV_NO_DEEP=1",
                                     "IRMV_FRONT_FASTX=0", "IRMV_FRONT_DIRECT=0", "IRMV_FRONT_TILE8=0",
-                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1", "IRMV_NMS_CLASSWALK=0"])
+                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1", "IRMV_NMS_CLASSWALK=0", "IRMV_NO_PF4=1"])
 def test_every_remaining_switch_is_bitwise_the_default(blob, monkeypatch, switch):
     """The environment switches that select between implementations of the same arithmetic (where the copies ride, where the
     results land, where candidates are found, which launches are merged): heads and detections of a batched step, of
@@ -653,6 +653,38 @@ def test_eight_wave_tiles_on_maps_that_do_not_tile(blob, monkeypatch):
     for mode in ("IRMV_FORCE_W8", "IRMV_FORCE_NT8"):
         for a, b in zip(heads[mode], heads["IRMV_NO_W8"]):
             assert np.array_equal(a, b), mode
+
+
+def test_four_steps_ahead_staging_is_bitwise_the_others(blob, monkeypatch):
+    """The LDS family's staging four (image, chunk) steps ahead (`_p4`: the 128-channel layers of a lone frame, all of a
+    workgroup's steps in flight) on every layer that has the tile, for single-frame and four-frame steps at 640 (20 x 20 and
+    40 x 40 maps, stride 1 and 2) and 416 (13 x 13 / 26 x 26: row runs with partial last blocks): heads and detections are
+    those of an engine without it (IRMV_NO_PF4=1), bit for bit."""
+    for net in (640, 416):
+        outs = {}
+        for mode in ("IRMV_FORCE_PF4", "IRMV_NO_PF4"):
+            monkeypatch.delenv("IRMV_FORCE_PF4", raising=False)
+            monkeypatch.delenv("IRMV_NO_PF4", raising=False)
+            monkeypatch.setenv(mode, "1")
+            with YoloEngine(None, (1280, 1024), weights_blob=blob, net_size=net, num_slots=4) as e:
+                n1 = [st["name"] for st in e.profile(0, 1)]
+                n4 = [st["name"] for st in e.profile(0, 4)]
+                if mode == "IRMV_FORCE_PF4":
+                    assert sum(n.endswith("_p4") for n in n1) >= 6 and sum(n.endswith("_p4") for n in n4) >= 6, (n1, n4)
+                else:
+                    assert not any("_p4" in n for n in n1 + n4)
+                for s in range(4):
+                    _load(e, s, frames.synthetic_frame(40 + s))
+                e.submit(0, 4); e.wait()
+                res = [e.read_head(s).copy() for s in range(4)] + [_raw_tuple(e.read_raw(s)) for s in range(4)]
+                e.detect(2)
+                res += [e.read_head(2).copy(), _raw_tuple(e.read_raw(2))]
+                outs[mode] = res
+        for a, b in zip(outs["IRMV_FORCE_PF4"], outs["IRMV_NO_PF4"]):
+            if isinstance(a, tuple):
+                assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:])), net
+            else:
+                assert np.array_equal(a, b), net
 
 
 def test_merged_head_first_stage_is_bitwise_the_separate_convs(blob, frame0, monkeypatch):
