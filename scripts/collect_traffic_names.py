@@ -7,8 +7,9 @@ def internal_name(sym):
     m = (re.search(r"conv3x3_lds_kernel<(\d), (\d), (\d), (true|false), (\d)>", sym) or
          re.search(r"conv3x3_lds_kernelILi(\d)ELi(\d)ELi(\d)ELb([01])ELi(\d)E", sym))
     if m:   # images-per-workgroup is a launch argument, not part of the symbol: the "_iN" suffix of the bench name is dropped
-        # template tail <..., PF2, CM, NWV, WR, PP>: WR > 0 = the weights-resident kernel (round 3), PP its ping-pong form
-        t = re.search(r"conv3x3_lds_kernelILi\dELi\dELi\dELb[01]ELi\dELb[01]ELi\dELi\dELi(\d)ELb([01])E", sym)
+        # template tail <..., PF, CM, NWV, WR, PP>: WR > 0 = the weights-resident kernel (round 3), PP its ping-pong form
+        # (PF: a bool until the second half of round 4, an int since -- both manglings are read)
+        t = re.search(r"conv3x3_lds_kernelILi\dELi\dELi\dELb[01]ELi\dEL[bi]\dELi\dELi\dELi(\d)ELb([01])E", sym)
         if t and t.group(1) != "0":
             return f"conv3x3s{m.group(1)}_wres" + ("_pp" if t.group(2) == "1" else "") + ("+1x1" if m.group(5) != "0" else "")
         return f"conv3x3s{m.group(1)}_lds_mt{m.group(2)}_nt{m.group(3)}" + ("+1x1" if m.group(5) != "0" else "")
