@@ -240,6 +240,13 @@ def _class_walk_heads():
     lone[:, 64:78] = -20.0
     lone[4242, 64 + 7] = 3.0
     out["one candidate"] = lone
+    iso = np.zeros((8400, 86), np.float32)                   # 300 candidates with point-like boxes (DFL mass on bin 0): nobody suppresses
+    iso[:, 64:78] = -20.0                                    # anybody -> 300 survivors, cut at max_det (256: the last records reach into
+    iso[:, 0:64:16] = 12.0                                   # the LDS that held the keypoint logits)
+    iso[:, 78:] = 0.25 + 0.3 * rng.standard_normal((8400, 8))
+    pick = rng.choice(8400, 300, replace=False)
+    iso[pick, 64 + rng.integers(0, 14, 300)] = rng.uniform(0.0, 3.0, 300).astype(np.float32)
+    out["300 isolated candidates"] = iso
     out["cluster of 700 in front (first walk starts over)"] = _clustered_head(rng, 700, 500)
     out["cluster of 400 in front of 800"] = _clustered_head(rng, 400, 800)
     return out
@@ -265,6 +272,8 @@ def test_class_walk_path_on_crafted_heads(blob, monkeypatch, cap, md):
                     assert raw["n_candidates"] == 500 and 1 < raw["num_dets"] < 500
                 if name == "fourteen classes, ~ 400":
                     assert 300 < raw["n_candidates"] <= 512
+                if name == "300 isolated candidates":
+                    assert raw["n_candidates"] == 300 and raw["num_dets"] == min(md, 300 if cap >= 300 else cap)
     for name in _class_walk_heads():
         a, b = got[("1", name)], got[("0", name)]
         assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:])), name
