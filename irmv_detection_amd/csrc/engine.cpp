@@ -292,11 +292,11 @@ irmv_engine::~irmv_engine()
     if (dbg_dev) {   // diagnostic: phase cycles of the last nms_pnp launch per slot (100 MHz s_memtime-independent clock64)
         std::vector<long long> h((size_t)cfg.num_slots * 16);
         if (hipMemcpy(h.data(), dbg_dev, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
-            for (int s = 0; s < cfg.num_slots && s < 4; s++)
+            for (int s = 0; s < cfg.num_slots && s < std::max(4, atoi(getenv("IRMV_NMS_STAMPS") ? getenv("IRMV_NMS_STAMPS") : "0")); s++)   // IRMV_NMS_STAMPS=<n>: the first n slots (at least four)
             {
                 const long long *t = &h[(size_t)s * 16];
-                fprintf(stderr, "[nms stamps] slot %d: keys %lld select %lld decode %lld sort %lld gather+classes %lld rows %lld walk %lld kpts %lld pnp %lld store %lld cycles; n=%lld kept=%lld\n", s,
-                        t[7] - t[0], t[8] - t[7], t[9] - t[8], t[1] - t[9], t[10] - t[1], t[2] - t[10], t[3] - t[2], t[11] - t[3], t[12] - t[11], t[4] - t[12], t[5], t[6]);
+                fprintf(stderr, "[nms stamps] slot %d: keys %lld select %lld decode %lld sort %lld gather+classes %lld rows %lld walk %lld kpts %lld pnp %lld store %lld cycles; total %lld; n=%lld kept=%lld\n", s,
+                        t[7] - t[0], t[8] - t[7], t[9] - t[8], t[1] - t[9], t[10] - t[1], t[2] - t[10], t[3] - t[2], t[11] - t[3], t[12] - t[11], t[4] - t[12], t[4] - t[0], t[5], t[6]);
             }
     }
     for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
