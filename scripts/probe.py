@@ -11,7 +11,7 @@ modes:
     s2       stride-2 layers at a 416 net: LDS kernel vs chunk-major direct kernel vs its deep variant, tap by tap (NET=<size>)
     crash    every hand-off path once, a line before each phase: which one survives `rocprofv3 --kernel-trace`
     repro    the round-1 fault sequence (engine A, engine B created / used / destroyed, A replays with upload): run ONCE per change
-    headerr  GPU head vs the fp32 and the fp16-emulating oracle per frame; box / keypoint differences per stride
+    headerr  GPU head vs the fp32 oracle over FRAMES (64) synthetic frames + rm_test.jpg: max / p99 / median per Detect level and branch, the worst three taken apart tap by tap
     light    classical light extraction inside a bbox-only step, and the extract_armors API on realistic ROIs
     harness  tests/cpp/yolo_test: the reference yolo_engine_benchmark shape (100 warm-ups, 30 runs x 10)
     summary  one line per bench JSON: probe.py summary <bench.json> [label]
@@ -20,6 +20,10 @@ modes:
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the CPU oracle is OpenMP code: a GPU box shows every host CPU but grants a share of them, and a team as large as the visible
+# count, spinning at its barriers, takes seconds per forward pass (tests/conftest.py does the same before liboracle.so loads)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, len(os.sched_getaffinity(0))))))
 
 
 def cmd_tune(ARGS):
@@ -258,45 +262,50 @@ def cmd_repro(ARGS):
 
 
 def cmd_headerr(ARGS):
-    """GPU head vs the fp32 and the fp16-emulating oracle per frame; box / keypoint differences per stride"""
+    """GPU head vs the fp32 oracle over FRAMES synthetic frames (default 64: frames 0 .. 63) + rm_test.jpg: max / p99 / median per Detect level and branch, the three worst frames taken apart tap by tap (tests/head_sweep.py); BOXES=1 adds box / keypoint differences per stride"""
     import os, sys
     import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import head_sweep
     from irmv_detection_amd import frames, weights
     from irmv_detection_amd.engine import YoloEngine
     from oracle import oracle
     oracle.build()
     blob = weights.synthetic_blob(0)
     net = oracle.Net(blob)
-    worst = {8: [0, 0], 16: [0, 0], 32: [0, 0]}
-    tot = [0, 0, 0]
+    n = int(os.environ.get("FRAMES", "64"))
+    first = int(os.environ.get("FIRST", "0"))
+    def frame_of(label):
+        if isinstance(label, int):
+            return frames.synthetic_frame(label)
+        from PIL import Image
+        return np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "rm_test.jpg")).convert("RGB"))
+    def it():
+        for label in list(range(first, first + n)) + ["rm_test"]:
+            yield label, frame_of(label)
     with YoloEngine(None, (1280, 1024), weights_blob=blob) as e:
-        for fi in [0, 1, 2, 3, 10, 11, 101, 103, 200, 263, 327]:
-            f = frames.synthetic_frame(fi)
-            e.get_src_image_buffer()[:] = f
-            e.detect()
-            hg = e.read_head(0)
-            raw = e.read_raw(0)
-            x = oracle.preprocess(f, 640)
-            h32, h16 = net.forward(x), net.forward(x, emulate_fp16=True)
-            d = [np.abs(hg - h32), np.abs(hg - h16), np.abs(h16 - h32)]
-            for i in range(3):
-                tot[i] = max(tot[i], float(d[i].max()))
-            a = np.unravel_index(np.argmax(d[0]), d[0].shape)
-            lvl = 0 if a[0] < 6400 else (1 if a[0] < 8000 else 2)
-            sec = "box" if a[1] < 64 else ("cls" if a[1] < 78 else "kpt")
-            print(f"frame {fi:3d}: gpu-fp32 {d[0].max():.4f} (mean {d[0].mean():.5f}; worst at level {lvl} {sec} ch {a[1]}, value {h32[a]:.2f})  "
-                  f"gpu-emu {d[1].max():.4f}  emu-fp32 {d[2].max():.4f}  | box {d[0][:, :64].max():.4f} cls {d[0][:, 64:78].max():.4f} kpt {d[0][:, 78:].max():.4f}", flush=True)
-            ref = oracle.decode_nms(h32, 640, 14, 8)
-            gi = {(int(a_), int(c)): i for i, (a_, c) in enumerate(zip(raw["anchors"], raw["classes"]))}
-            for i, (a_, c) in enumerate(zip(ref["anchors"], ref["classes"])):
-                j = gi.get((int(a_), int(c)))
-                if j is None:
-                    continue
-                s = 8 if a_ < 6400 else (16 if a_ < 8000 else 32)
-                worst[s][0] = max(worst[s][0], float(np.abs(raw["boxes"][j] - ref["boxes"][i]).max()))
-                worst[s][1] = max(worst[s][1], float(np.abs(raw["kpts"][j] - ref["kpts"][i]).max()))
-    print("max over frames: gpu-fp32 %.4f  gpu-emu %.4f  emu-fp32 %.4f" % tuple(tot))
-    print("shared survivors, max |d box| / |d kpt| px per stride:", worst)
+        res = head_sweep.sweep(e, net, it(), oracle)
+        head_sweep.report(res)
+        worst = sorted(res["per_frame"], key=lambda t: -t[1])[:int(os.environ.get("ATTRIBUTE", "3"))]
+        for label, _ in worst:
+            head_sweep.attribute(e, net, label, frame_of(label), oracle)
+        if os.environ.get("BOXES") == "1":
+            worst_px = {8: [0, 0], 16: [0, 0], 32: [0, 0]}
+            for fi in range(first, first + min(n, 16)):
+                f = frames.synthetic_frame(fi)
+                e.get_src_image_buffer()[:] = f
+                e.detect()
+                raw = e.read_raw(0)
+                ref = oracle.decode_nms(net.forward(oracle.preprocess(f, 640)), 640, 14, 8)
+                gi = {(int(a_), int(c)): i for i, (a_, c) in enumerate(zip(raw["anchors"], raw["classes"]))}
+                for i, (a_, c) in enumerate(zip(ref["anchors"], ref["classes"])):
+                    j = gi.get((int(a_), int(c)))
+                    if j is None:
+                        continue
+                    s = 8 if a_ < 6400 else (16 if a_ < 8000 else 32)
+                    worst_px[s][0] = max(worst_px[s][0], float(np.abs(raw["boxes"][j] - ref["boxes"][i]).max()))
+                    worst_px[s][1] = max(worst_px[s][1], float(np.abs(raw["kpts"][j] - ref["kpts"][i]).max()))
+            print("shared survivors, max |d box| / |d kpt| px per stride:", worst_px)
 
 
 def cmd_light(ARGS):

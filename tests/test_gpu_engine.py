@@ -3,10 +3,15 @@ reference's YoloEngine / PnPSolver interface), against the CPU oracle.
 
 Stated tolerances (DESIGN.md "Parity"):
   preprocess            bit-exact (integer taps; fp16 of v/255 is unique)
-  activations / head    fp16 storage, fp32 accumulate: |d| <= 3e-2 abs on logits of magnitude ~20 vs the fp32 oracle
-                        (measured over 11 frames: 0.028; the oracle's own fp16-emulating mode sits 0.029 from its fp32
-                        mode).  Against the fp16-EMULATING oracle the bound is 2 x 3e-2: two fp16 pipelines with
-                        different accumulation orders, each within 3e-2 of the fp32 result (measured 0.036)
+  activations / head    fp16 storage, fp32 accumulate, vs the fp32 oracle, stated on frames nobody picked
+                        (test_head_error_over_unchosen_frames: synthetic frames 0 .. 63 + the reference's rm_test.jpg):
+                        every frame's max |d| <= HEAD_TOL = 4e-2 on logits of magnitude ~20; at least 90 % of the frames
+                        <= HEAD_P90 = 3e-2 (SURVEY 8c's figure); median frame <= 2.5e-2.  Measured in round 5: max 0.0348
+                        (frame 17), p90 0.0279, median 0.0209 -- the accumulated rounding of ~25 fp16 activation tensors
+                        (relative rms error 3e-4 behind model.0, 1e-3 behind model.15: tests/head_sweep.py), which is also
+                        where the oracle's own fp16-emulating mode sits (0.029 over 11 frames).  Against that
+                        fp16-EMULATING mode the bound is EMU_TOL = 6e-2: two fp16 pipelines with different accumulation
+                        orders (measured 0.045)
   decode / NMS / kpts   bit-exact on identical head tensors (survivor set AND order);
                         end to end vs the fp32 oracle: survivor set IDENTICAL on the margin fixtures
                         (tests/golden/margin_cases.json: every decode / NMS decision clear of fp16 noise), boxes
@@ -32,7 +37,10 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
-HEAD_TOL = 3e-2
+HEAD_TOL = 4e-2     # any frame's max |d head| vs the fp32 oracle
+HEAD_P90 = 3e-2     # ... and what 90 % of the frames stay under (SURVEY 8c's 3e-2 is not a bound over all frames: two of 65 exceed it)
+HEAD_MEDIAN = 2.5e-2
+EMU_TOL = 6e-2      # vs the oracle's fp16-emulating mode (another fp16 pipeline)
 KPT_TOL = 0.75
 SCORE_TOL = 5e-3
 
@@ -116,11 +124,11 @@ def test_network_taps_and_head_vs_oracle(eng, onet, frame0):
         _, t_o = onet.forward(x, emulate_fp16=True, tap=tap)
         t_g = eng.read_tap(tap, 0)
         assert t_g.shape == t_o.shape, tap
-        assert np.abs(t_g - t_o).max() <= 2 * HEAD_TOL, tap     # fp16-emulating oracle: see the module docstring
+        assert np.abs(t_g - t_o).max() <= EMU_TOL, tap     # fp16-emulating oracle: see the module docstring
         assert np.abs(t_g - t_o).mean() <= 2e-3, tap
     h_g = eng.read_head(0)
     assert _report_head("frame 0, 640 net", float(np.abs(h_g - onet.forward(x)).max())) <= HEAD_TOL   # vs the fp32 oracle: the contract
-    assert np.abs(h_g - onet.forward(x, emulate_fp16=True)).max() <= 2 * HEAD_TOL     # vs another fp16 pipeline
+    assert np.abs(h_g - onet.forward(x, emulate_fp16=True)).max() <= EMU_TOL     # vs another fp16 pipeline
 
 
 def test_network_on_golden_block_input(blob, onet):
@@ -145,6 +153,32 @@ def test_network_on_golden_block_input(blob, onet):
     print(f"golden branch: {'committed net_blocks.npz head applied' if exact else 'fixture input not reproduced by the u8 round trip: oracle-on-the-fly only'}")
     if exact:
         assert np.abs(head - g["head"]).max() <= HEAD_TOL
+
+
+def test_head_error_over_unchosen_frames(blob, onet, rm_test_image, capsys):
+    """The head tolerance as a statement over frames nobody picked: synthetic frames 0 .. 63 (every seed in order) and the
+    reference's own test/rm_test.jpg, through detect() on the reference node's engine shape.  Prints max / p99 / median per
+    Detect level and branch (the distribution goes to the test log) and asserts the bound DESIGN section 5 states."""
+    import head_sweep
+    def it():
+        for fi in range(64):
+            yield fi, frames.synthetic_frame(fi)
+        yield "rm_test", rm_test_image
+    lines = []
+    with YoloEngine(None, (1280, 1024), weights_blob=blob) as e:
+        res = head_sweep.sweep(e, onet, it(), oracle, log=lines.append)
+    mx, p99, med = head_sweep.report(res, log=lines.append)
+    with capsys.disabled():
+        print("\n" + "\n".join(lines[-11:]))
+    per = np.array([m for _, m in res["per_frame"]])
+    assert len(per) == 65
+    assert mx <= HEAD_TOL, sorted(res["per_frame"], key=lambda t: -t[1])[:5]
+    assert np.quantile(per, 0.9) <= HEAD_P90
+    assert med <= HEAD_MEDIAN
+    # nothing vacuous: most frames carry structure (frames without an armor give a near-constant head: |d| ~ 4e-4)
+    assert (per > 5e-3).sum() >= 55
+    # the keypoint branch, whose logits feed pixel coordinates directly (2 * v * stride), stays an order of magnitude tighter
+    assert max(max(res["cells"][(li, "kpt")]) for li in range(3)) <= 1e-2
 
 
 # ---------------------------------------------------------------- decode / NMS / keypoints

@@ -78,7 +78,7 @@ def test_engine_int8_blob_equals_dequantised_fp16_blob(int8_blob, net):
     assert heads[0][1]["num_dets"] == heads[1][1]["num_dets"] and np.array_equal(heads[0][1]["boxes"], heads[1][1]["boxes"])
     ho = oracle.Net(int8_blob).forward(oracle.preprocess(f, net))
     assert heads[0][0].shape == ho.shape == ((net // 8) ** 2 + (net // 16) ** 2 + (net // 32) ** 2, 86)
-    assert np.abs(heads[0][0] - ho).max() <= 3e-2
+    assert np.abs(heads[0][0] - ho).max() <= 4e-2      # HEAD_TOL of tests/test_gpu_engine.py
     d = oracle.decode_nms(heads[0][0], net, 14, 8)
     assert d["num_dets"] == heads[0][1]["num_dets"] and np.array_equal(d["boxes"], heads[0][1]["boxes"])
 

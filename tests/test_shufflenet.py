@@ -13,7 +13,8 @@ from irmv_detection_amd import arch, frames, weights
 from oracle import oracle
 from torch_ref import TorchNet
 
-HEAD_TOL = 3e-2
+HEAD_TOL = 4e-2   # tests/test_gpu_engine.py: the bound over any frame
+EMU_TOL = 6e-2
 
 
 @pytest.fixture(scope="module")
@@ -103,11 +104,11 @@ def test_engine_taps_and_head_vs_oracle(sblob, net):
                 continue                     # block-internal tensors exist (shape-checked by the read); the oracle taps block outputs
             _, t_o = on.forward(x, emulate_fp16=True, tap=tap)
             assert t_g.shape == t_o.shape, tap
-            assert np.abs(t_g - t_o).max() <= 2 * HEAD_TOL, tap
+            assert np.abs(t_g - t_o).max() <= EMU_TOL, tap
             assert np.abs(t_g - t_o).mean() <= 2e-3, tap
         h = e.read_head(0)
     assert np.abs(h - on.forward(x)).max() <= HEAD_TOL
-    assert np.abs(h - on.forward(x, emulate_fp16=True)).max() <= 2 * HEAD_TOL
+    assert np.abs(h - on.forward(x, emulate_fp16=True)).max() <= EMU_TOL
 
 
 @pytest.mark.gpu
