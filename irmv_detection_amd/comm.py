@@ -66,9 +66,12 @@ def shard_frames(total_frames: int, rank: int, world: int) -> List[int]:
 
 
 def id_file() -> str:
-    """Where rank 0 leaves the communicator id: keyed by the launcher (parent) pid and the rendezvous port, so that two
-    launches on one node never see each other's file."""
-    return os.path.join(tempfile.gettempdir(), f"irmv_comm_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.id")
+    """Where rank 0 leaves the communicator id: keyed by the launcher (parent) pid, the rendezvous port and -- under an
+    elastic launcher, whose agent (and with it the parent pid and the port) survives a worker restart -- the run id and the
+    restart count, so that neither two launches on one node nor two generations of one launch ever see each other's file."""
+    gen = "_".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"))
+    gen = "".join(c if c.isalnum() else "-" for c in gen)[:48]
+    return os.path.join(tempfile.gettempdir(), f"irmv_comm_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{gen}.id")
 
 
 _T_START = time.time()      # this process's start (import) time: id files much older than it belong to an earlier launch
@@ -141,22 +144,33 @@ class FileReduce:
                 os.remove(old)
         return vals
 
-    def close(self) -> None:
+    def close(self, ack_timeout_s: float = 30.0) -> None:
         """Two closing rounds: once the second is complete on a rank, every rank has READ the first, so each rank removes
-        its own files of every round up to the first; rank 0 then gives the peers a moment to read the second round's files
-        and removes whatever of this launch is left (its prefix is unique to the launch)."""
+        its own files of every round up to the first and then ACKNOWLEDGES -- a `done.<rank>` file written after its second
+        gather returned, i.e. after it has read every file of the last round.  Rank 0 sweeps the launch's prefix (unique to
+        the launch) only once every acknowledgement is there; past `ack_timeout_s` it leaves the last round's few bytes to
+        the temp directory instead of pulling a file from under a descheduled peer.  The job has succeeded by the time
+        close() runs: a peer that disappears during it costs nothing but those files (no CommError out of here)."""
         import glob
-        self.gather(0.0)
-        self.gather(0.0)
+        try:
+            self.gather(0.0, timeout_s=ack_timeout_s)
+            self.gather(0.0, timeout_s=ack_timeout_s)
+        except CommError:
+            return
         for q in range(1, self.seq):
             path = f"{self.base}.r{q}.{self.rank}"
             if os.path.exists(path):
                 os.remove(path)
-        if self.rank == 0:
-            time.sleep(0.3)
-        else:
+        with open(f"{self.base}.done.{self.rank}", "w"):
+            pass
+        if self.rank != 0:
             return
-        for path in glob.glob(glob.escape(self.base) + ".r*"):
+        t0 = time.time()
+        while not all(os.path.exists(f"{self.base}.done.{r}") for r in range(self.world)):
+            if time.time() - t0 > ack_timeout_s:
+                return
+            time.sleep(0.002)
+        for path in glob.glob(glob.escape(self.base) + ".r*") + glob.glob(glob.escape(self.base) + ".done.*"):
             try:
                 os.remove(path)
             except OSError:
@@ -214,7 +228,8 @@ class Comm:
                     _check(L.irmv_comm_init_rank(uid, self.world, self.rank, self.device, C.byref(self._h)))
                 except (CommError, OSError) as e:
                     ok, self.native_error = 0.0, str(e)
-            self.native = min(self._files.gather(ok, timeout_s=600.0 if ok > 0.5 else 60.0)) > 0.5
+            stage2_wait = float(os.environ.get("IRMV_COMM_STAGE2_WAIT_S", "60"))
+            self.native = min(self._files.gather(ok, timeout_s=600.0 if ok > 0.5 else stage2_wait)) > 0.5
             if not self.native:
                 import sys
                 print(f"[irmv_comm] rank {self.rank}: RCCL communicator not available on every rank"

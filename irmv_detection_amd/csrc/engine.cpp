@@ -1325,6 +1325,16 @@ static void cfg_name(const ConvCfg &c, char *buf, int n)
 // changes a single output bit (tests/test_gpu_engine.py::test_tile_choice_is_bitwise_neutral).
 static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int count, ConvArgs &a, bool fused = false);
 
+// A candidate of the autotuner: the layer's own configuration with a tile shape and family, every launch-time option off
+// (the candidates below switch on the one or two they are about).
+static ConvCfg tile_cfg(const ConvCfg &base, int mt, int nt, bool lds, int ipw)
+{
+    ConvCfg c = base;
+    c.mt = mt; c.nt = nt; c.lds = lds; c.ipw = ipw;
+    c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+    return c;
+}
+
 static int autotune_convs(irmv_engine *e)
 {
     const char *env = getenv("IRMV_AUTOTUNE");
@@ -1367,7 +1377,7 @@ static int autotune_convs(irmv_engine *e)
             // implementations -- the LDS kernel, the direct kernel walking K chunk-major, its deep-prefetch form
             const char *force_s2 = getenv("IRMV_FORCE_S2");
             char key[160];
-            snprintf(key, sizeof key, "gfx950|%d.%d.%d.%d.%d.%d|%dx%d>%dx%d|c%d.%d.%d.%d>%d|ld%d.%d.%d|n%d|%d", op.cfg.ks, op.cfg.stride,
+            snprintf(key, sizeof key, "gfx950.t5|%d.%d.%d.%d.%d.%d|%dx%d>%dx%d|c%d.%d.%d.%d>%d|ld%d.%d.%d|n%d|%d", op.cfg.ks, op.cfg.stride,   // ".t5": the table format / flag set of round 5 -- entries of another round's file never match, so they are re-tuned, not reinterpreted
                      (int)op.cfg.cin16, op.cfg.act, (int)op.cfg.out_f32, (int)lds_ok, a.Hin, a.Win, a.Hout, a.Wout, a.s0.C, a.s1.C, a.s0.shift,
                      a.s1.shift, a.cout_pad, a.s0.ld, a.s1.ld, a.out_ld, counts[pass], (a.res ? 1 : 0) + 2 * a.n2);
             // A cached choice (this process, or the IRMV_TUNE_CACHE file) is replayed only if it is a legal tile of THIS
@@ -1398,7 +1408,7 @@ static int autotune_convs(irmv_engine *e)
                     if (ok && h.deep) ok = (h.mt == 1 || (h.mt == 2 && h.nt == 1)) && !op.cfg.cin16 && !op.cfg.out_f32 && op.cfg.act == 1;
                     if (ok && h.ct) ok = op.w_lds[0] != nullptr;
                     if (ok && h.pf2) ok = h.lds && h.mt == 1 && !want_fuse;
-                    if (ok && h.pf4) ok = !getenv("IRMV_NO_PF4") && h.lds && !h.pf2 && !h.cm && !h.w8 && !h.wr && h.mt == 1 && h.nt == 1 && !want_fuse;
+                    if (ok && h.pf4) ok = !getenv("IRMV_NO_PF4") && h.lds && !h.pf2 && !h.cm && !h.w8 && !h.wr && h.mt == 1 && h.nt == 1 && h.ipw == 1 && op.cin >= 128 && !want_fuse;   // (the only form the tuner generates, times and the bitwise tests cover)
                     if (ok && h.cm && h.nt != 8) ok = !getenv("IRMV_NO_CM") && h.lds && !h.pf2 && h.cm == h.ipw && h.nt == 4 && ((h.mt == 1 && (!want_fuse || h.cm == 4)) || (h.mt == 2 && h.cm == 2));
                     if (ok && h.w8 && h.nt == 4) ok = !getenv("IRMV_NO_W8") && h.lds && op.cfg.stride == 2 && !want_fuse && !h.pf2 && (h.mt == 1 || h.mt == 2) &&
                                                      (h.cm == 0 || (h.cm == h.ipw && ((h.mt == 2 && h.cm == 2) || (h.mt == 1 && h.cm == 4))));
@@ -1455,8 +1465,7 @@ static int autotune_convs(irmv_engine *e)
                         for (int ipw = 1; ipw <= (fam == 1 ? std::min(4, counts[pass]) : 1); ipw *= 2) {
                             if (op.cout_pad % (16 * nt) != 0) continue;
                             if (want_fuse && nt != 4) continue;
-                            ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = nt; c.lds = fam == 1; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                            ConvCfg c = tile_cfg(op.cfg, mt, nt, fam == 1, ipw);
                             TRY(time_cfg(c));
                         }
                 // LDS family, smallest pixel tile, staging two steps ahead (layers whose step is shorter than a memory round trip)
@@ -1464,15 +1473,15 @@ static int autotune_convs(irmv_engine *e)
                     for (int nt = 1; nt <= 4; nt *= 2)
                         for (int ipw = 1; ipw <= std::min(4, counts[pass]); ipw *= 2) {
                             if (op.cout_pad % (16 * nt) != 0) continue;
-                            ConvCfg c = op.cfg;
-                            c.mt = 1; c.nt = nt; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = true; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                            ConvCfg c = tile_cfg(op.cfg, 1, nt, true, ipw);
+                            c.pf2 = true;
                             TRY(time_cfg(c));
                         }
                 // ... and four steps ahead: layers of four or more chunks on maps small enough for four register sets (a lone frame's
                 // 20 x 20 layers: every step of a workgroup in flight at once)
                 if (fam == 1 && !want_fuse && !getenv("IRMV_NO_PF4") && op.cin >= 128 && op.w_lds[0]) {
-                    ConvCfg c = op.cfg;
-                    c.mt = 1; c.nt = 1; c.lds = true; c.ipw = 1; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = true; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                    ConvCfg c = tile_cfg(op.cfg, 1, 1, true, 1);
+                    c.pf4 = true;
                     TRY(time_cfg(c));
                     if (getenv("IRMV_FORCE_PF4") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests: wherever it exists
                 }
@@ -1481,8 +1490,8 @@ static int autotune_convs(irmv_engine *e)
                     for (int mt = 1; mt <= 2; mt *= 2)
                         for (int ipw = 2; ipw <= std::min(mt == 1 ? 4 : 2, counts[pass]); ipw *= 2) {
                             if (want_fuse && mt == 1 && ipw == 2) continue;   // (no instantiation with the fused 1x1)
-                            ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = ipw; c.w8 = false; c.wr = false; c.pp = false;
+                            ConvCfg c = tile_cfg(op.cfg, mt, 4, true, ipw);
+                            c.cm = ipw;
                             TRY(time_cfg(c));
                             if (getenv("IRMV_FORCE_CM") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                         }
@@ -1493,8 +1502,8 @@ static int autotune_convs(irmv_engine *e)
                         for (int ipw = 1; ipw <= std::min(4, counts[pass]); ipw *= 2)
                             for (int cmv = 0; cmv < 2; cmv++) {
                                 if (cmv && !((mt == 2 && ipw == 2) || (mt == 1 && ipw == 4))) continue;
-                                ConvCfg c = op.cfg;
-                                c.mt = mt; c.nt = 4; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = cmv ? ipw : 0; c.w8 = true; c.wr = false; c.pp = false;
+                                ConvCfg c = tile_cfg(op.cfg, mt, 4, true, ipw);
+                                c.w8 = true; c.cm = cmv ? ipw : 0;
                                 TRY(time_cfg(c));
                                 if (getenv("IRMV_FORCE_W8") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                             }
@@ -1505,8 +1514,8 @@ static int autotune_convs(irmv_engine *e)
                     for (int ipw = 1; ipw <= std::min(4, counts[pass]); ipw *= 2)
                         for (int cmv = 0; cmv < 2; cmv++) {
                             if (cmv && ipw != 2) continue;
-                            ConvCfg c = op.cfg;
-                            c.mt = 1; c.nt = 8; c.lds = true; c.ipw = ipw; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = cmv ? 2 : 0; c.w8 = true; c.wr = false; c.pp = false;
+                            ConvCfg c = tile_cfg(op.cfg, 1, 8, true, ipw);
+                            c.w8 = true; c.cm = cmv ? 2 : 0;
                             TRY(time_cfg(c));
                             if (getenv("IRMV_FORCE_NT8") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                         }
@@ -1522,8 +1531,8 @@ static int autotune_convs(irmv_engine *e)
                         const int cand[3] = {ipw1, (ipw1 + 1) / 2, std::min(counts[pass], 2 * ipw1)};
                         for (int k = 0; k < 3; k++) {
                             if (k > 0 && (cand[k] == cand[0] || (k == 2 && cand[2] == cand[1]))) continue;
-                            ConvCfg c = op.cfg;
-                            c.mt = 2; c.nt = 4; c.lds = true; c.ipw = cand[k]; c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = true; c.pp = ppv != 0;
+                            ConvCfg c = tile_cfg(op.cfg, 2, 4, true, cand[k]);
+                            c.wr = true; c.pp = ppv != 0;
                             TRY(time_cfg(c));
                         }
                     }
@@ -1532,15 +1541,15 @@ static int autotune_convs(irmv_engine *e)
                 if (const char *fw = getenv("IRMV_FORCE_WRES"); fw && fam == 1 && counts[pass] >= 2 && op.w_lds[2]) {
                     const int v = atoi(fw);
                     for (int ppv = v > 0 ? 1 : 0; ppv >= 0; ppv--) {
-                        ConvCfg c = op.cfg;
-                        c.mt = 2; c.nt = 4; c.lds = true; c.ipw = std::max(1, std::min(counts[pass], v < 0 ? -v : v)); c.deep = false; c.ct = false; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = true; c.pp = ppv != 0;
+                        ConvCfg c = tile_cfg(op.cfg, 2, 4, true, std::max(1, std::min(counts[pass], v < 0 ? -v : v)));
+                        c.wr = true; c.pp = ppv != 0;
                         if (conv_wres_bytes(a, op.cfg.stride, c.pp) > 0 && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; break; }
                     }
                 }
                 // 1x1 layers: the persistent pointwise kernel (same operands, same k order as the direct kernel)
                 if (conv_pw_eligible(op.cfg, a) && !getenv("IRMV_NO_PW")) {
-                    ConvCfg c = op.cfg;
-                    c.mt = 2; c.nt = 4; c.lds = false; c.ipw = 1; c.deep = false; c.ct = false; c.pw = true; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                    ConvCfg c = tile_cfg(op.cfg, 2, 4, false, 1);
+                    c.pw = true;
                     TRY(time_cfg(c));
                     if (getenv("IRMV_FORCE_PW") && run_conv(op, c, a, counts[pass], e->stream)) { best = 0.f; best_cfg = c; }   // parity tests
                     // ... and its multi-block form: one workgroup runs a pixel tile against 2 / 4 output-channel blocks (input read once)
@@ -1557,8 +1566,8 @@ static int autotune_convs(irmv_engine *e)
                     for (int mt = 1; mt <= 4; mt *= 2)
                         for (int nt = 1; nt <= 4; nt *= 2) {
                             if (op.cout_pad % (16 * nt) != 0) continue;
-                            ConvCfg c = op.cfg;
-                            c.mt = mt; c.nt = nt; c.lds = false; c.ipw = 1; c.deep = false; c.ct = true; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                            ConvCfg c = tile_cfg(op.cfg, mt, nt, false, 1);
+                            c.ct = true;
                             TRY(time_cfg(c));
                         }
                 // single-frame steps: the latency variants of the direct kernel (deep prefetch ring), same rule.
@@ -1568,8 +1577,8 @@ static int autotune_convs(irmv_engine *e)
                     const int tiles[4][2] = {{1, 1}, {2, 1}, {1, 2}, {1, 4}};
                     for (auto &t : tiles) {
                         if (op.cout_pad % (16 * t[1]) != 0) continue;
-                        ConvCfg c = op.cfg;
-                        c.mt = t[0]; c.nt = t[1]; c.lds = false; c.ipw = 1; c.deep = true; c.ct = lds_ok; c.pw = false; c.pf2 = false; c.pf4 = false; c.cm = 0; c.w8 = false; c.wr = false; c.pp = false;
+                        ConvCfg c = tile_cfg(op.cfg, t[0], t[1], false, 1);
+                        c.deep = true; c.ct = lds_ok;
                         TRY(time_cfg(c));
                     }
                 }

@@ -22,6 +22,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // model.0 reads the unscaled image: its epilogue scales the accumulator (one fma, the bias rides in it); the Detect
 // finals (no activation, fp32 out) undo the scale the same way: out = acc * ln 2 + bias.  Read-backs of activation
 // tensors multiply by ln 2 on the host (engine.cpp read_tensor_f32).
+// RANGE: a stored activation overflows fp16 where log2(e) * |a| > 65504, i.e. at |a| > 45 403 instead of 65 504 (it becomes
+// +-inf, as a plain fp16 pipeline's does above 65 504; nothing saturates).  Trained detection networks keep activations
+// within a few hundred; tests/test_gpu_engine.py::test_activation_range_under_the_log2e_scale pins the behaviour on both sides
+// of the edge (finite and equal to the fp16-emulating oracle's at 4e4, inf past 45.4e3).  sppf_pool's v_pk_max_f16 assumes
+// no NaN: an inf is ordered like any value, a NaN (inf - inf in a later layer) can only arise past that edge.
 constexpr float kActScale = 1.44269504088896341f;    // log2(e)
 constexpr float kActUnscale = 0.693147180559945309f; // ln 2
 // Rounding is pinned by hand.  Left to the compiler, (half)(y * r) becomes v_pk_mul_f32 + v_cvt_pk_f16_f32 (two roundings)
@@ -83,6 +88,13 @@ __device__ __forceinline__ void tile_image(int id, int tiles, int batch, int xcd
 inline int xcd_image_order()
 {
     const char *v = getenv("IRMV_XCD_IMAGES");
+    return (v && v[0] == '0') ? 0 : 1;
+}
+
+// lockstep resident-weight 3x3 kernel: waves 4 .. 7 defer their epilogue by one image (k_conv.hip); IRMV_WRES_STAGGER=0: off
+inline int wres_stagger()
+{
+    const char *v = getenv("IRMV_WRES_STAGGER");
     return (v && v[0] == '0') ? 0 : 1;
 }
 

@@ -284,18 +284,6 @@ constexpr int PS = 96;                                       // bytes per pixel 
 static_assert(R1N % 16 == 0 && R3N % 16 == 0, "tile regions are whole MFMA tiles");
 }  // namespace
 
-#ifndef IRMV_EXP
-#define IRMV_EXP 0   // 4: phase stamps for scripts/probes/c2f_probe.cpp
-#endif
-#ifndef IRMV_ABL
-#define IRMV_ABL 0   // timing ablations (results wrong): 1 no input loads in phase 1, 2 phases 2 + 3 skipped, 4 phase 4 skipped, 8 no SiLU in phase 1
-#endif
-#if IRMV_EXP & 4
-__device__ unsigned long long g_c2f_phase[16];
-#define C2F_STAMP(k) do { const long long t_ = clock64(); t_acc[k] += t_ - t_prev; t_prev = t_; } while (0)
-#else
-#define C2F_STAMP(k) do { } while (0)
-#endif
 // MODE 0 = AB, 1 = A, 2 = B.  KS1 = k-steps of cv1 (Cin / 32).
 template <int MODE, int KS1, bool SHORTCUT>
 __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int xcd)
@@ -319,11 +307,6 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
     __shared__ float s_bias[32 + 32 + 64];
     if (tid < 32) { s_bias[tid] = a.b_m1[tid]; s_bias[32 + tid] = a.b_m2[tid]; }
     if (MODE != 1 && tid < 64) s_bias[64 + tid] = a.b_cv2[tid];
-#if IRMV_EXP & 4
-    long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const long long t_begin = clock64();
-    long long t_prev = t_begin;
-#endif
 
     u32x4 Y01[2][2];   // mode B only
     static_assert(R3N / 16 == 8, "two output tiles per wave");
@@ -406,12 +389,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
             for (int u = 0; u < 2; u++) {
                 o[u] = zero8;   // outside the image y1 is the bottleneck's zero padding
                 if (inside && (u == 1 || want_y0)) {
-                    if (IRMV_ABL & 8) {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) { o[u][i] = (half_t)acc[2 * u][i]; o[u][4 + i] = (half_t)acc[2 * u + 1][i]; }
-                    } else {
-                        o[u] = silu_pack8(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3], acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]);
-                    }
+                    o[u] = silu_pack8(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3], acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]);
                 }
             }
             *reinterpret_cast<half8 *>(s_in + m * PS + g * 16) = o[1];
@@ -430,7 +408,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
         {
             uint32_t o0, o1;
             row_off(wave, o0, o1);
-            if (!(IRMV_ABL & 1)) issue(o0, o1, Bn);
+            issue(o0, o1, Bn);
         }
 #pragma unroll
         for (int i = 0; i < NROWT; i++) {
@@ -441,11 +419,11 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
                 uint32_t o0, o1;
                 if (i + 1 < NROWT) {
                     row_off(t + 4, o0, o1);
-                    if (!(IRMV_ABL & 1)) issue(o0, o1, Bn);
+                    issue(o0, o1, Bn);
                 } else if (has_col) {
                     const int gy = oy0 - 2 + ly_c, gx = ox0 - 2 + lx_c;
                     px_off(gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gx < 0 ? 0 : (gx >= W ? W - 1 : gx), o0, o1);
-                    if (!(IRMV_ABL & 1)) issue(o0, o1, Bn);
+                    issue(o0, o1, Bn);
                 }
             }
             const int gy = oy0 - 2 + t;
@@ -490,9 +468,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
             if (e < R1N * 4) *reinterpret_cast<u32x4 *>(s_in + m * PS + (e & 3) * 16) = keep_if((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W, v[i]);
         }
     }
-    C2F_STAMP(0);
     __syncthreads();
-    C2F_STAMP(1);
 
     // ---- 2: m.cv1 (3x3, 32 -> 32, SiLU) on the 10 x 18 region ----
     {
@@ -505,7 +481,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
         float bias[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) bias[i] = s_bias[g * 8 + i];
-        for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : (R2N + 15) / 16); t += 4) {
+        for (int t = wave; t < (R2N + 15) / 16; t += 4) {
             int ly, lx;
             const bool mv = region_tile_px<R2H, R2W>(t, r, ly, lx);
             const int m = ly * R2W + lx;
@@ -525,9 +501,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
             }
         }
     }
-    C2F_STAMP(2);
     __syncthreads();
-    C2F_STAMP(3);
 
     // ---- 3: m.cv2 (3x3, 32 -> 32, SiLU) [+ shortcut] on the tile ----
     {
@@ -540,7 +514,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
         float bias[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) bias[i] = s_bias[32 + g * 8 + i];
-        for (int t = wave; t < ((IRMV_ABL & 2) ? 0 : R3N / 16); t += 4) {
+        for (int t = wave; t < R3N / 16; t += 4) {
             const int m = t * 16 + r;
             const int ly = m / FW, lx = m - ly * FW;
             const uint8_t *base = s_t + (ly * R2W + lx) * PS + g * 16;
@@ -569,9 +543,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
         }
     }
     if constexpr (MODE == 1) return;
-    C2F_STAMP(4);
     __syncthreads();
-    C2F_STAMP(5);
 
     // ---- 4: cv2 (1x1 over the concat, -> 64, SiLU) -> block output ----
     {
@@ -588,7 +560,7 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
 #pragma unroll
             for (int i = 0; i < 8; i++) bias[u * 8 + i] = s_bias[64 + u * 32 + g * 8 + i];
         half_t *out = a.out + (size_t)b * H * W * a.out_ld;
-        for (int t = wave; t < ((IRMV_ABL & 4) ? 0 : R3N / 16); t += 4) {
+        for (int t = wave; t < R3N / 16; t += 4) {
             const int m = t * 16 + r;
             const int ly = m / FW, lx = m - ly * FW;
             const int gy = oy0 + ly, gx = ox0 + lx;
@@ -621,14 +593,6 @@ __global__ __launch_bounds__(256) void c2f32_kernel(C2f32Args a, int batch, int 
             }
         }
     }
-#if IRMV_EXP & 4
-    C2F_STAMP(6);
-    if (tid == 0) {
-        for (int k = 0; k < 7; k++) atomicAdd(&g_c2f_phase[k], (unsigned long long)t_acc[k]);
-        atomicAdd(&g_c2f_phase[8], (unsigned long long)(clock64() - t_begin));
-        atomicAdd(&g_c2f_phase[10], 1ull);
-    }
-#endif
 }
 
 static std::mutex g_c2f_attr_mu;

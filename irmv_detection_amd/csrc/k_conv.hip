@@ -750,24 +750,6 @@ constexpr int lds_pmax(int stride, int mt, bool tile2d, int wr = 0, int pf = 0)
     return pf == 2 ? (stride == 1 ? 4 : 8) : (wr ? 4 : ((tile2d && stride == 1) ? (mt == 4 ? 8 : 4) : 12));
 }
 
-#ifndef IRMV_ABL
-#define IRMV_ABL 0   // timing ablations of conv3x3_lds_kernel (scripts/probes/conv_probe.cpp); results are wrong with any bit set:
-#endif               // 1 weights staged once, 2 patch staged once, 4 no MFMAs, 8 no SiLU, 16 no output stores,
-                     // 32 the k-step's MFMAs as half as many v_mfma_f32_32x32x16_f16 on the same fragment registers (same matrix-pipe
-                     //    time, half the issue slots: what that shape would buy before anything is built for it)
-#ifndef IRMV_EXP
-#define IRMV_EXP 0   // structural experiments of the same probe: 1 late epilogue, 2 staggered second workgroup per CU
-#endif
-#if IRMV_EXP & 4
-__device__ unsigned long long g_phase[16];
-#endif
-#if IRMV_EXP & 32
-__device__ unsigned long long g_pp[2][8];   // ping-pong groups: cycles of wave 0 of each group per phase, summed over workgroups
-#endif
-#if IRMV_EXP & 2
-__device__ int g_cu_arrivals[4096];
-__device__ int g_stagger_sleeps = 0;
-#endif
 #ifndef IRMV_LDS_WAVES
 #define IRMV_LDS_WAVES 2   // minimum waves per SIMD the register allocation aims at (A/B: scripts/gpu_stage.sh abwaves)
 #endif
@@ -775,7 +757,7 @@ __device__ int g_stagger_sleeps = 0;
 // (conv3x3_lds_multi below); conv3x3_lds_kernel itself is the thin wrapper behind it.
 template <int STRIDE, int MT, int NT, bool TILE2D, int N2, int PF = 0, int CM = 0, int NWV = 4, int WR = 0, bool PP = false>
 __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t *wl, int tiles_x, int tiles_y, int twc_log2, int a_patch_bytes, int ipw, int batch,
-                                                 int wg_x, int wg_y, int grid_x, int grid_y)
+                                                 int wg_x, int wg_y, int grid_x, int grid_y, int stagger = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
@@ -917,7 +899,6 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         const size_t off = (size_t)l_im * img_stride + (size_t)l_chunk * 32;
 #pragma unroll
         for (int i = 0; i < PMAX; i++) {
-            if ((IRMV_ABL & 2) && (l_im | l_chunk)) break;
             // (conditional loads cost nothing here: the next thing this wave does with the ring is write ALL of it to LDS, so
             // the conservative wait counts they cause -- see conv_mfma_kernel -- wait for nothing that is not needed; made
             // unconditional, the unused piece slots of the small tiles were extra loads: measured 10 - 15 % slower at MT = 1)
@@ -926,7 +907,6 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         }
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
-            if ((IRMV_ABL & 1) && (l_im | l_chunk)) break;
             if (CM > 0 && l_im != 0) break;                // chunk-major: the chunk's weights are in LDS already
             const int e = tid + i * NTH;
             if (e < 9 * NT * 64) w[i] = wsrc[(size_t)l_chunk * (9 * NT * 64) + e];
@@ -940,12 +920,10 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
     auto write_lds = [&](const half8 (&p)[PMAX], const half8 (&w)[WPT]) {
 #pragma unroll
         for (int i = 0; i < PMAX; i++) {
-            if ((IRMV_ABL & 2) && (c_im | c_chunk)) break;
             if (use_p[i]) *reinterpret_cast<half8 *>(s_patch + dst_p[i]) = p[i];
         }
 #pragma unroll
         for (int i = 0; i < WPT; i++) {
-            if ((IRMV_ABL & 1) && (c_im | c_chunk)) break;
             if (CM > 0 && c_im != 0) break;
             const int e = tid + i * NTH;
             if (e < 9 * NT * 64) s_w[e] = w[i];
@@ -1028,16 +1006,13 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
                             vals[i] = accx[mt][2 * u][i];
                             vals[4 + i] = accx[mt][2 * u + 1][i];
                         }
-                        if (IRMV_ABL & 8) {
-#pragma unroll
-                            for (int i = 0; i < 8; i++) ov[u][i] = (half_t)vals[i];
-                        } else if (a.res) {   // (rounding pinned: irmv_common.hpp)
+                        if (a.res) {   // (rounding pinned: irmv_common.hpp)
 #pragma unroll
                             for (int i = 0; i < 8; i++) ov[u][i] = silu_add_res(vals[i], (float)rv8[mt][u][i]);
                         } else {
                             ov[u] = silu_pack8(vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], vals[6], vals[7]);
                         }
-                        if constexpr (N2 == 0) if (!(IRMV_ABL & 16) || ov[u][0] == (half_t)123.0f) *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = ov[u];
+                        if constexpr (N2 == 0) *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = ov[u];
                     }
                     if constexpr (N2 > 0) {
                         // With the paired-tile packing lane (g, r) now holds channels u*32 + 8g + [0, 8) of pixel r: exactly the
@@ -1138,7 +1113,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
-                    if (!(IRMV_ABL & 4)) accx[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[nt], B[mt], accx[mt][nt], 0, 0, 0);
+                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[nt], B[mt], accx[mt][nt], 0, 0, 0);
             if constexpr (SPREAD) __builtin_amdgcn_sched_barrier(0x38f);   // everything but vector-memory instructions may cross
         }
         if constexpr (SPREAD) {
@@ -1153,15 +1128,6 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         constexpr int KS = (WR > 0 ? WR : 1) * 9;
         auto &accx = acc[0];
         half8 A[2][NT], B[2][MT];
-#if IRMV_ABL & 32
-        typedef float f32x16 __attribute__((ext_vector_type(16)));
-        constexpr int NC32 = MT * NT >= 4 ? MT * NT / 4 : 1;
-        f32x16 c32[NC32];   // the wave's MT x NT x 4 accumulator registers as 32 x 32 tiles
-#pragma unroll
-        for (int t = 0; t < MT * NT / 4; t++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) c32[t][i] = accx[(t * 4 + i / 4) / NT][(t * 4 + i / 4) % NT][i % 4];
-#endif
         auto frag = [&](auto ks_, half8 (&Af)[NT], half8 (&Bf)[MT]) {
             constexpr int ks = decltype(ks_)::value, c = ks / 9, tap = ks % 9, kh = tap / 3, kw = tap % 3;
             const unsigned char *s_pl = s_patch + (size_t)c * a_patch_bytes + (kh * PW + kw) * pix_stride(STRIDE);
@@ -1176,38 +1142,18 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
             constexpr int ks = decltype(ks_)::value;
             if constexpr (ks + 1 < KS) frag(std::integral_constant<int, ks + 1>{}, A[(ks + 1) & 1], B[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-#if IRMV_ABL & 32
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt += 2)   // (timing only: these fragments are not laid out for this shape)
-                    c32[(mt * NT + nt) / 4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks & 1][nt], B[ks & 1][mt], c32[(mt * NT + nt) / 4], 0, 0, 0);
-#else
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
-                    if (!(IRMV_ABL & 4)) accx[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks & 1][nt], B[ks & 1][mt], accx[mt][nt], 0, 0, 0);
-#endif
+                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks & 1][nt], B[ks & 1][mt], accx[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto run = [&](auto self, auto ks_) -> void {
             constexpr int ks = decltype(ks_)::value;
             if constexpr (ks < KS) { step(ks_); self(self, std::integral_constant<int, ks + 1>{}); }
         };
-#if IRMV_EXP & 16
-        __builtin_amdgcn_s_setprio(1);
-#endif
         run(run, std::integral_constant<int, 0>{});
-#if IRMV_EXP & 16
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#if IRMV_ABL & 32
-#pragma unroll
-        for (int t = 0; t < MT * NT / 4; t++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) accx[(t * 4 + i / 4) / NT][(t * 4 + i / 4) % NT][i % 4] = c32[t][i];
-#endif
     };
     auto mma_step = [&]() {
         taps(std::false_type{}, I0{});
@@ -1218,71 +1164,6 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
             c_im++;
         }
     };
-#if IRMV_EXP & 2
-    {   // experiment: the second workgroup to arrive on a CU starts half a step late
-        __shared__ int s_late;
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-            const unsigned idx = ((xcc & 15) << 8) | ((hw >> 8) & 0xff);   // xcc | se, sh, cu
-            s_late = atomicAdd(&g_cu_arrivals[idx], 1) & 1;
-        }
-        __syncthreads();
-        if (s_late)
-            for (int i = 0; i < g_stagger_sleeps; i++) __builtin_amdgcn_s_sleep(32);
-    }
-#endif
-#if IRMV_EXP & 1
-    if constexpr (!PF2) {   // experiment: an image's epilogue runs at the start of the next step, between its staging barrier and its loads
-        issue_loads(rp[0], rw[0]);
-        int pend_im = -1;
-        for (int s = 0; s < steps; s++) {
-            write_lds(rp[0], rw[0]);
-            __syncthreads();
-            if (pend_im >= 0) { store_tile(pend_im, I0{}); pend_im = -1; }
-            if (s + 1 < steps) issue_loads(rp[0], rw[0]);
-            taps(std::false_type{}, I0{});
-            __syncthreads();
-            if (++c_chunk == chunks) { pend_im = img + c_im; c_chunk = 0; c_im++; }
-        }
-        if (pend_im >= 0) store_tile(pend_im, I0{});
-        return;
-    }
-#endif
-#if IRMV_EXP & 4
-    if constexpr (!PF2) {   // experiment: phase cycles of wave 0 (s_memtime), summed over the workgroups
-        long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const long long t_begin = clock64(), w_begin = wall_clock64();
-        long long t_prev = t_begin;
-        auto stamp = [&](int k) { const long long t = clock64(); t_acc[k] += t - t_prev; t_prev = t; };
-        issue_loads(rp[0], rw[0]);
-        stamp(0);
-        for (int s = 0; s < steps; s++) {
-            write_lds(rp[0], rw[0]);
-            stamp(1);
-            __syncthreads();
-            stamp(2);
-#if IRMV_EXP & 8
-            if (s + 1 < steps) issue_loads(rp[0], rw[0]);
-            stamp(3);
-            taps(std::false_type{}, I0{});
-#else
-            stamp(3);
-            taps(std::true_type{}, I0{});
-#endif
-            stamp(4);
-            __syncthreads();
-            stamp(5);
-            if (++c_chunk == chunks) { store_tile(img + c_im, I0{}); c_chunk = 0; c_im++; stamp(6); }
-        }
-        if (tid == 0) {
-            for (int k = 0; k < 7; k++) atomicAdd(&g_phase[k], (unsigned long long)t_acc[k]);
-            atomicAdd(&g_phase[8], (unsigned long long)(clock64() - t_begin));
-            atomicAdd(&g_phase[9], (unsigned long long)(wall_clock64() - w_begin));
-            atomicAdd(&g_phase[10], 1ull);
-        }
-        return;
-    }
-#endif
     if constexpr (WR > 0) {
         // ---- weights resident: stage all WR chunk slabs once, then one step per image ----
         {
@@ -1330,49 +1211,38 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
             write_wr();
             if (nimg > 1) issue_wr(1);
             __syncthreads();
-#if IRMV_EXP & 32
-            long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            long long t_prev = clock64();
-            const long long t_begin = t_prev;
-            auto stamp = [&](int k) { const long long t = clock64(); t_acc[k] += t - t_prev; t_prev = t; };
-#else
-            auto stamp = [&](int) {};
-#endif
             for (int s = 0; s < nimg; s++) {
                 ksteps_wr();                                                          // MFMA phase (the other group: load phase)
-                stamp(0);
                 __syncthreads();
-                stamp(1);
                 store_tile(img + s, I0{});                                            // load phase (the other group: MFMA phase)
-                stamp(2);
                 if (s + 1 < nimg) {
-                    if (!(IRMV_ABL & 2)) write_wr();
-                    stamp(3);
-                    if (s + 2 < nimg && !(IRMV_ABL & 2)) issue_wr(s + 2);
-                    stamp(4);
+                    write_wr();
+                    if (s + 2 < nimg) issue_wr(s + 2);
                 }
                 __syncthreads();
-                stamp(5);
             }
             if (sub == 0) __builtin_amdgcn_s_barrier();
-#if IRMV_EXP & 32
-            if (tidp == 0) {
-                for (int k = 0; k < 6; k++) atomicAdd(&g_pp[sub][k], (unsigned long long)t_acc[k]);
-                atomicAdd(&g_pp[sub][6], (unsigned long long)(clock64() - t_begin));
-                atomicAdd(&g_pp[sub][7], (unsigned long long)nimg);
-            }
-#endif
             return;
         }
+        // Lockstep form (maps that do not tile into the ping-pong blocks).  Left alone, the two waves of a SIMD reach their
+        // MFMA phase, their fragment reads and their SiLU epilogue together: the matrix pipe idles through both epilogues.
+        // STAGGER (round 5; MI355X_MICROARCH.md "Two waves per SIMD", item 9): the second-dispatched half of the workgroup
+        // (waves NWV / 2 ..) defers the epilogue of image s to the start of step s + 1, behind the barrier that releases
+        // patch s + 1 -- its vector work then runs beside the first half's MFMAs, and the first half's epilogue beside the
+        // tail of its MFMAs.  The sums stay in their accumulator registers across the barriers; same operations on the
+        // same operands, only later: bit-identical.  Barriers per image unchanged (two).
+        const bool late = stagger && wave >= NWV / 2;
         issue_wr(0);
         for (int s = 0; s < nimg; s++) {
-            if (!(IRMV_ABL & 2) || s == 0) write_wr();
+            write_wr();
             __syncthreads();
-            if (s + 1 < nimg && !(IRMV_ABL & 2)) issue_wr(s + 1);
+            if (late && s > 0) store_tile(img + s - 1, I0{});
+            if (s + 1 < nimg) issue_wr(s + 1);
             ksteps_wr();
             __syncthreads();
-            store_tile(img + s, I0{});
+            if (!late) store_tile(img + s, I0{});
         }
+        if (late) store_tile(img + nimg - 1, I0{});
     } else if constexpr (CM > 0) {
         static_assert(!PF2 && CM <= 4, "chunk-major order: one step of staging lead, at most four images");
         auto each_image = [&](auto f) {
@@ -1403,7 +1273,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
         for (int s = 0; s < steps; s++) {
             write_lds(rp[0], rw[0]);
             __syncthreads();
-            if constexpr (MT == 4 && !(IRMV_EXP & 8)) {
+            if constexpr (MT == 4) {
                 taps(std::true_type{}, I0{});                          // next step's loads spread over the taps
             } else {   // small tiles: the burst is short and the spread costs more than it saves (measured)
                 if (s + 1 < steps) issue_loads(rp[0], rw[0]);
@@ -1443,9 +1313,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(IRMV_L
     // by the stride-2 and 80 x 80 layers, profiles/r04_traffic.json)
     const int wg_tiles = PP ? (tiles_x * tiles_y + 1) / 2 : tiles_x * tiles_y, groups = (batch + ipw - 1) / ipw;
     int rem, grp;
-    tile_image(blockIdx.x, wg_tiles * nblocks, groups, xcd, rem, grp);
+    tile_image(blockIdx.x, wg_tiles * nblocks, groups, xcd & 1, rem, grp);   // xcd: bit 0 = image order, bit 1 = stagger (lockstep resident-weight form)
     const int nblk = rem / wg_tiles, tile = rem - nblk * wg_tiles;
-    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF, CM, NWV, WR, PP>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, grp * wg_tiles + tile, nblk, wg_tiles * groups, nblocks);
+    conv3x3_lds_body<STRIDE, MT, NT, TILE2D, N2, PF, CM, NWV, WR, PP>(a, wl, tiles_x, tiles_y, twc_log2, a_patch_bytes, ipw, batch, grp * wg_tiles + tile, nblk, wg_tiles * groups, nblocks, (xcd >> 1) & 1);
 }
 
 // Several independent 3x3 layers in ONE launch (the Detect branches of the three levels in a single-frame step: fifteen
@@ -1524,7 +1394,7 @@ static void launch_lds_inst(const ConvArgs &a, const half_t *wl, int batch, int 
     const int wg_tiles = PP ? (g.tiles_x * g.tiles_y + 1) / 2 : g.tiles_x * g.tiles_y;   // ping-pong: two tile positions per workgroup
     const int nblocks = a.cout_pad / (16 * NT);
     hipLaunchKernelGGL((conv3x3_lds_kernel<STRIDE, MT, NT, TILE2D, N2, PF, CM, NWV, WR, PP>), dim3(wg_tiles * groups * nblocks), dim3(64 * NWV), g.bytes, s, a,
-                       wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch, nblocks, xcd_image_order());
+                       wl, g.tiles_x, g.tiles_y, g.twc_log2, g.patch_bytes, ipw, batch, nblocks, xcd_image_order() | (wres_stagger() << 1));
 }
 
 // Weights-resident variant: Cin = 64 -> 64 channels, stride 1.  ONE 8-wave workgroup per CU keeps the

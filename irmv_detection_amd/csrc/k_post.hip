@@ -1237,6 +1237,7 @@ __global__ __launch_bounds__(1024) void nms_pnp_kernel(PostArgs a)
             }
         }
         __syncthreads();
+        if (kept == 0) { IRMV_STAMP(11); IRMV_STAMP(12); }   // (diagnostic stamps: a frame without survivors has no keypoint / PnP phase; without these its two slots printed garbage)
         if (j < kept) {           // pair-uniform
             // the record's fields go to the LDS staging as they are produced (lane 0 of the pair): held in registers across the
             // solver they spilled

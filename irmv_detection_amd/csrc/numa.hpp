@@ -77,7 +77,9 @@ inline bool bind_thread_to_node(int node)
 }
 
 // RAII: bind the calling thread to `node` and prefer its memory for the allocations made inside the scope (the first touch
-// of a hipHostMallocNumaUser allocation then lands there); restores the previous affinity and the default policy.
+// of a hipHostMallocNumaUser allocation then lands there); restores the previous affinity and the memory policy the thread
+// HAD (a process started under numactl --membind / --interleave, or one that called set_mempolicy itself, keeps it;
+// MPOL_DEFAULT only where the query failed).
 class ScopedNode {
   public:
     explicit ScopedNode(int node)
@@ -86,6 +88,7 @@ class ScopedNode {
         have_prev_ = sched_getaffinity(0, sizeof prev_, &prev_) == 0;
         bound_ = bind_thread_to_node(node);
         if (node < 1024) {
+            have_prev_policy_ = syscall(SYS_get_mempolicy, &prev_mode_, prev_mask_, (unsigned long)(sizeof prev_mask_ * 8), nullptr, 0ul) == 0;
             unsigned long mask[16] = {0};
             mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
             policy_ = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, (unsigned long)(sizeof mask * 8)) == 0;
@@ -93,7 +96,15 @@ class ScopedNode {
     }
     ~ScopedNode()
     {
-        if (policy_) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+        if (policy_) {
+            bool restored = false;
+            if (have_prev_policy_) {
+                bool any = false;
+                for (unsigned long w : prev_mask_) any = any || w != 0;
+                restored = syscall(SYS_set_mempolicy, prev_mode_, any ? prev_mask_ : nullptr, any ? (unsigned long)(sizeof prev_mask_ * 8) : 0ul) == 0;
+            }
+            if (!restored) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+        }
         if (bound_ && have_prev_) (void)sched_setaffinity(0, sizeof prev_, &prev_);
     }
     bool bound() const { return bound_; }
@@ -103,7 +114,9 @@ class ScopedNode {
 
   private:
     cpu_set_t prev_;
-    bool have_prev_ = false, bound_ = false, policy_ = false;
+    int prev_mode_ = 0;
+    unsigned long prev_mask_[16] = {0};
+    bool have_prev_ = false, bound_ = false, policy_ = false, have_prev_policy_ = false;
 };
 
 // NUMA node that holds the page of `p` (move_pages as a query); < 0: not known (page not present, call not permitted)

@@ -1,4 +1,5 @@
-// Timing probe for c2f32_kernel<0, 6, false> (model.15 at a 640 net) outside the engine; -DIRMV_EXP=4 adds phase stamps.
+// Timing probe for c2f32_kernel<0, 6, false> (model.15 at a 640 net) outside the engine.  (The ablation / phase-stamp switches these probes drove inside the kernels -- IRMV_ABL, IRMV_EXP -- were
+// taken out of the product sources in round 5: their results are in DESIGN.md sections 4c, 4f, 8.)
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include scripts/probes/c2f_probe.cpp -o c2f_probe ; ./c2f_probe [batch=64]
 #include "../../irmv_detection_amd/csrc/k_c2f.hip"
 
@@ -49,19 +50,6 @@ int main(int argc, char **argv)
     CK(hipEventRecord(e1, st));
     CK(hipStreamSynchronize(st));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-#if IRMV_EXP & 4
-    {
-        unsigned long long z[16] = {0}, h[16];
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(irmv::g_c2f_phase), z, sizeof(z)));
-        irmv::launch_c2f32(0, false, a, B, st);
-        CK(hipStreamSynchronize(st));
-        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(irmv::g_c2f_phase), sizeof(h)));
-        const double n = (double)h[10];
-        static const char *nm[7] = {"1 cv1 (weights, input, 15 tiles)", "barrier", "2 m.cv1 (weights, 12 tiles)", "barrier", "3 m.cv2 (weights, 8 tiles)", "barrier", "4 cv2 (weights, 8 tiles, stores)"};
-        printf("  per workgroup (wave 0), %g workgroups: total %.0f cycles\n", n, h[8] / n);
-        for (int k = 0; k < 7; k++) printf("    %-36s %9.0f cycles  %5.1f %%\n", nm[k], h[k] / n, 100.0 * h[k] / h[8]);
-    }
-#endif
-    printf("ABL=%d EXP=%d c2f32_ab 80x80 cin 192 B=%d: %.2f us\n", IRMV_ABL, IRMV_EXP, B, ms * 1e3 / reps);
+    printf("c2f32_ab 80x80 cin 192 B=%d: %.2f us\n", B, ms * 1e3 / reps);
     return 0;
 }

@@ -1,6 +1,7 @@
-// Timing probe for conv3x3_lds_kernel on one layer shape, outside the engine: compile with -DIRMV_ABL=<bits> to switch
-// parts of the kernel off (k_conv.hip) and see what each costs.  Results of an ablated build are wrong by construction.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -DIRMV_ABL=0 scripts/probes/conv_probe.cpp -o conv_probe
+// Timing probe for conv3x3_lds_kernel on one layer shape, outside the engine.  (Rounds 2 - 4 drove ablation switches inside
+// the kernel from here -- IRMV_ABL / IRMV_EXP: weights or patch staged once, no MFMAs, no SiLU, no stores, late epilogue,
+// staggered second workgroup, phase stamps; results in DESIGN.md sections 4c, 4f.  The switches left the product sources in round 5.)
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -I include scripts/probes/conv_probe.cpp -o conv_probe
 //   ./conv_probe [S=80] [Cin=64] [batch=64] [mt=4] [nt=4] [ipw=4]
 #include "../../irmv_detection_amd/csrc/k_conv.hip"
 
@@ -37,39 +38,15 @@ int main(int argc, char **argv)
     for (int i = 0; i < 5; i++)
         if (!irmv::launch_conv_lds(1, mt, nt, ipw, a, d_w, B, st, false)) { fprintf(stderr, "not eligible\n"); return 2; }
     CK(hipStreamSynchronize(st));
-#if IRMV_EXP & 2
-    {
-        const int sleeps = argc > 7 ? atoi(argv[7]) : 0;
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(irmv::g_stagger_sleeps), &sleeps, sizeof(int)));
-    }
-#endif
     const int reps = 50;
     CK(hipEventRecord(e0, st));
     for (int i = 0; i < reps; i++) {
-#if IRMV_EXP & 2
-        void *cnt = nullptr;
-        CK(hipGetSymbolAddress(&cnt, HIP_SYMBOL(irmv::g_cu_arrivals)));
-        CK(hipMemsetAsync(cnt, 0, 4096 * 4, st));
-#endif
         irmv::launch_conv_lds(1, mt, nt, ipw, a, d_w, B, st, false);
     }
     CK(hipEventRecord(e1, st));
     CK(hipStreamSynchronize(st));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-#if IRMV_EXP & 4
-    {
-        unsigned long long z[16] = {0}, h[16];
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(irmv::g_phase), z, sizeof(z)));
-        irmv::launch_conv_lds(1, mt, nt, ipw, a, d_w, B, st, false);
-        CK(hipStreamSynchronize(st));
-        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(irmv::g_phase), sizeof(h)));
-        const double n = (double)h[10];
-        static const char *nm[7] = {"prologue+first loads", "wait loads + LDS writes", "barrier 1", "issue loads", "taps (LDS reads + MFMA)", "barrier 2", "epilogue"};
-        printf("  per workgroup (wave 0), %g workgroups: total %.0f cycles, %.2f us wall -> %.2f GHz\n", n, h[8] / n, h[9] / n * 0.01, (double)h[8] / ((double)h[9] * 10.0));
-        for (int k = 0; k < 7; k++) printf("    %-26s %9.0f cycles  %5.1f %%\n", nm[k], h[k] / n, 100.0 * h[k] / h[8]);
-    }
-#endif
     const double us = ms * 1e3 / reps, fl = 2.0 * B * S * S * Cout * Cin * 9;
-    printf("EXP=%d sleeps=%s ABL=%d S=%d Cin=%d B=%d mt%d nt%d i%d: %.2f us  %.1f TFLOP/s\n", IRMV_EXP, argc > 7 ? argv[7] : "-", IRMV_ABL, S, Cin, B, mt, nt, ipw, us, fl / us * 1e-6);
+    printf("S=%d Cin=%d B=%d mt%d nt%d i%d: %.2f us  %.1f TFLOP/s\n", S, Cin, B, mt, nt, ipw, us, fl / us * 1e-6);
     return 0;
 }

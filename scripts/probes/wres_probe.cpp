@@ -1,5 +1,5 @@
 // Timing + bitwise probe of the weights-resident 3x3 kernel (k_conv.hip, WR = 2) against the chunked LDS kernel on one layer
-// shape (Cin = 64 -> 64), outside the engine.  -DIRMV_ABL=<bits> as in conv_probe.cpp (results then differ by construction).
+// shape (Cin = 64 -> 64), outside the engine; IRMV_WRES_STAGGER=0 / 1 in the environment switches the lockstep form's stagger.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include scripts/probes/wres_probe.cpp -o build_probe/wres_probe
 //   ./wres_probe [S=80] [batch=64] [ref_mt=4] [ref_ipw=4] [ref_cm=0]
 #include "../../irmv_detection_amd/csrc/k_conv.hip"
@@ -50,7 +50,7 @@ int main(int argc, char **argv)
             best = ms < best ? ms : best;
         }
         const double us = best * 1e3 / 20;
-        printf("ABL=%d S=%d B=%d %-28s %8.2f us  %7.1f TFLOP/s\n", IRMV_ABL, S, B, name, us, fl / us * 1e-6);
+        printf("S=%d B=%d %-28s %8.2f us  %7.1f TFLOP/s\n", S, B, name, us, fl / us * 1e-6);
         return 0;
     };
     char nm[64];
@@ -68,22 +68,6 @@ int main(int argc, char **argv)
             CK(hipMemset(d_out, 0xff, n_out * 2));
             snprintf(nm, sizeof nm, "wres%s i%d", pp ? "_pp" : "", ipw);
             if (time_it([&] { return irmv::launch_conv_wres(ipw, a, d_w, B, st, pp != 0); }, nm)) return 1;
-#if IRMV_EXP & 32
-            if (pp) {
-                unsigned long long z[16] = {0}, h[16];
-                CK(hipMemcpyToSymbol(HIP_SYMBOL(irmv::g_pp), z, sizeof(z)));
-                irmv::launch_conv_wres(ipw, a, d_w, B, st, true);
-                CK(hipStreamSynchronize(st));
-                CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(irmv::g_pp), sizeof(h)));
-                static const char *pn[6] = {"MFMA phase", "barrier after MFMA", "epilogue", "ds_write patch", "issue loads", "barrier after load phase"};
-                for (int sgrp = 0; sgrp < 2; sgrp++) {
-                    const double steps = (double)h[sgrp * 8 + 7];
-                    printf("      group %d: %.0f image steps, %.0f cycles per step:", sgrp, steps, h[sgrp * 8 + 6] / steps);
-                    for (int k = 0; k < 6; k++) printf("  %s %.0f", pn[k], h[sgrp * 8 + k] / steps);
-                    printf("\n");
-                }
-            }
-#endif
             CK(hipMemcpy(h_out.data(), d_out, n_out * 2, hipMemcpyDeviceToHost));
             size_t bad = 0;
             for (size_t i = 0; i < n_out; i++) bad += memcmp(&h_ref[i], &h_out[i], 2) != 0;

@@ -51,7 +51,7 @@ idx = {i: e for i, e in enumerate(entries)}
 
 
 def candidates(key, v):
-    m = re.match(r"gfx950\|(\d)\.(\d)\.(\d)\.(\d)\.(\d)\.(\d)\|(\d+)x\d+>(\d+)x\d+\|c(\d+)\.(\d+)\.\d\.\d>(\d+)\|.*\|n(\d+)$", key)
+    m = re.match(r"gfx950[.t0-9]*\|(\d)\.(\d)\.(\d)\.(\d)\.(\d)\.(\d)\|(\d+)x\d+>(\d+)x\d+\|c(\d+)\.(\d+)\.\d\.\d>(\d+)\|.*\|n(\d+)$", key)
     ks, stride, cin16, act, f32, ldsfam, hin, hout, c0, c1, cout, n = (int(x) for x in m.groups())
     suffix, mt, nt, flags, ipw = v
     fused = suffix >= 2                      # a 1x1 rides in the epilogue: nt stays 4
@@ -73,7 +73,7 @@ def candidates(key, v):
 
 # heavy entries first: 80x80 and stride-2 3x3s, then 40x40, then the 1x1s, then 20x20
 def weight(key):
-    m = re.match(r"gfx950\|(\d)\.(\d).*\|(\d+)x\d+>(\d+)x", key)
+    m = re.match(r"gfx950[.t0-9]*\|(\d)\.(\d).*\|(\d+)x\d+>(\d+)x", key)
     ks, stride, hin, hout = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4))
     return -(hout * hout * (9 if ks == 3 else 2) * (2 if stride == 2 else 1))
 

@@ -155,6 +155,37 @@ def test_network_on_golden_block_input(blob, onet):
         assert np.abs(head - g["head"]).max() <= HEAD_TOL
 
 
+def test_activation_range_under_the_log2e_scale(blob):
+    """Activations are stored as log2(e) * a (irmv_common.hpp): the fp16 range ends at |a| = 65504 / log2(e) = 45 403 instead of
+    65 504.  Pinned on both sides of that edge with a model.0 whose channels 0 / 1 are constants (zero weights, bias 4.0e4 /
+    5.0e4): 4.0e4 comes back finite and equal to the fp16-emulating oracle's value to one fp16 step of the stored number
+    (32 * ln 2); 5.0e4 -- representable in a plain fp16 pipeline, which is what the oracle's emulating mode is -- overflows
+    to +inf here (documented deviation; nothing saturates, nothing faults, the step completes)."""
+    from irmv_detection_amd import weights
+    hdr, layers = weights.parse_blob(blob)
+    specs, tensors = [], []
+    for sp, w, b in layers:
+        w, b = w.copy(), b.copy()
+        if sp.name == "model.0.conv":
+            w[0:2] = 0
+            b[0], b[1] = 4.0e4, 5.0e4
+        specs.append(sp); tensors.append((w, b))
+    hot = weights.build_blob(specs, tensors, hdr["nc"], hdr["nk"], hdr["backbone"])
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    with YoloEngine(None, (64, 64), weights_blob=hot, net_size=64, rotate180=False) as e:
+        _load(e, 0, img)
+        e.detect()                                        # inf / NaN run through every later layer, NMS and PnP: no fault
+        t0 = e.read_tap("0", 0)
+        e.detect()
+    x = (img.astype(np.float32) / np.float32(255)).astype(np.float16).astype(np.float32).transpose(2, 0, 1)
+    _, o0 = oracle.Net(hot).forward(x, emulate_fp16=True, tap="0")
+    assert np.isfinite(t0[..., 0]).all() and np.abs(t0[..., 0] - o0[..., 0]).max() <= 32.0 * 0.7, (t0[0, 0, 0], o0[0, 0, 0])
+    assert np.isfinite(o0[..., 1]).all() and o0[0, 0, 1] > 4.9e4      # the plain fp16 pipeline still holds 5e4 ...
+    assert np.isposinf(t0[..., 1]).all()                                # ... the scaled one does not: +inf, not NaN, not a clamp
+    assert np.isfinite(t0[..., 2:]).all() and np.abs(t0[..., 2:] - o0[..., 2:]).max() <= EMU_TOL
+
+
 def test_head_error_over_unchosen_frames(blob, onet, rm_test_image, capsys):
     """The head tolerance as a statement over frames nobody picked: synthetic frames 0 .. 63 (every seed in order) and the
     reference's own test/rm_test.jpg, through detect() on the reference node's engine shape.  Prints max / p99 / median per
@@ -634,7 +665,7 @@ def test_resident_weight_kernels_are_bitwise_the_chunked_ones(blob, monkeypatch,
 @pytest.mark.parametrize("switch", ["IRMV_INLINE_COPIES=1", "IRMV_ZERO_COPY_RESULTS=0", "IRMV_SPLIT_SCAN=0", "IRMV_EMIT_SCAN=0",
                                     "IRMV_FUSED_HEAD=0", "IRMV_MERGE_HEAD0=0", "IRMV_GROUP_HEAD=0", "IRMV_NO_PF2=1", "IRMV_NO_DEEP=1",
                                     "IRMV_FRONT_FASTX=0", "IRMV_FRONT_DIRECT=0", "IRMV_FRONT_TILE8=0",
-                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1", "IRMV_NMS_CLASSWALK=0", "IRMV_NO_PF4=1"])
+                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1", "IRMV_NMS_CLASSWALK=0", "IRMV_NO_PF4=1", "IRMV_WRES_STAGGER=0"])
 def test_every_remaining_switch_is_bitwise_the_default(blob, monkeypatch, switch):
     """The environment switches that select between implementations of the same arithmetic (where the copies ride, where the
     results land, where candidates are found, which launches are merged): heads and detections of a batched step, of
