@@ -20,6 +20,7 @@ SOURCES = [
     ("k_pre.hip", []),
     ("k_front.hip", []),
     ("k_c2f.hip", []),
+    ("k_bneck.hip", []),
     ("k_conv.hip", []),
     ("k_post.hip", ["-ffp-contract=off"]),
     ("k_light.hip", ["-ffp-contract=off"]),

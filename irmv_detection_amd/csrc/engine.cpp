@@ -149,7 +149,7 @@ struct Tensor {
 
 struct SegRef { int t = -1, coff = 0, C = 0, shift = 0; };
 
-enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2, OP_C2F32, OP_DW, OP_SHUF, OP_SCAN };
+enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2, OP_C2F32, OP_DW, OP_SHUF, OP_SCAN, OP_BNECK };
 
 struct Op {
     OpKind kind;
@@ -177,6 +177,7 @@ struct Op {
     int fuse_next = -1;        // LDS 3x3 conv: index of the 1x1 op computed in its epilogue (Detect-head finals), -1 = none
     bool fused_away = false;   // preprocess / model.0 / model.1 when the fused front kernel runs them (kept for read-backs)
     int group = -1;            // single-frame steps: index into irmv_engine::head_groups of the one launch this conv rides in
+    int bneck = -1;            // single-frame steps: index of the OP_BNECK launch (k_bneck.hip) that computes this conv; OP_BNECK itself: 1 = kept
 };
 
 struct GraphKey {
@@ -264,6 +265,7 @@ struct irmv_engine {
     std::vector<std::vector<uint16_t>> dequant;   // int8 blobs: per layer fp16(q * scale), what LayerW::w points to
     std::vector<std::vector<uint16_t>> merged_w;  // Detect first-stage convs of a level concatenated along cout (single-frame engines)
     std::vector<std::vector<float>> merged_b;
+    bool bneck64 = true;       // single-frame steps run the 64-channel Bottlenecks of the C2f blocks (and their cv2) as one launch each (IRMV_BNECK64=0: off)
     bool merge_head0 = false;
 
     ~irmv_engine();
@@ -606,6 +608,54 @@ static int fuse_c2f32(irmv_engine *e, const std::string &prefix, int n, bool sho
     return IRMV_OK;
 }
 
+// Single-frame steps: a 64-channel Bottleneck (model.6 / 12 / 18 at a 640 net) as ONE launch, the block's last one together
+// with cv2 (k_bneck.hip).  The OP_BNECK ops stand behind the block's layer ops, which stay what batched steps run (and the
+// bit-exactness reference); a step of one frame skips the layers and runs the fused launches instead.
+static int fuse_bneck64(irmv_engine *e, const std::string &prefix, int n, bool shortcut, int cat, int out_t)
+{
+    if (!e->bneck64 || e->backbone != 0) return IRMV_OK;
+    const int last = (int)e->ops.size() - 1, first = last - (2 * n + 1);
+    if (n < 1 || n > 2 || first < 0) return IRMV_OK;
+    for (int i = first; i <= last; i++)
+        if (e->ops[i].kind != OP_CONV) return IRMV_OK;
+    const Op &c2 = e->ops[last];
+    bool ok = c2.cfg.ks == 1 && c2.cout == 128 && c2.cout_pad == 128 && c2.pair && c2.cin == (2 + n) * 64 && c2.ksteps == 2 * (2 + n) && c2.cfg.act == 1 &&
+              !c2.cfg.out_f32 && c2.s1.C == 0 && c2.s0.shift == 0 && c2.res_t < 0;
+    for (int i = first + 1; i < last && ok; i++) {
+        const Op &m = e->ops[i];
+        ok = m.cfg.ks == 3 && m.cfg.stride == 1 && m.cin == 64 && m.cout == 64 && m.pair && m.ksteps == 18 && m.cfg.act == 1 && !m.cfg.cin16 && m.w_lds[0] != nullptr &&
+             m.s1.C == 0 && m.s0.shift == 0;
+    }
+    if (!ok) return IRMV_OK;
+    const int bH = c2.Hin, bW = c2.Win;
+    for (int i = 0; i < n; i++) {
+        const int i_m1 = first + 1 + 2 * i, i_m2 = i_m1 + 1;
+        const bool with_cv2 = i == n - 1;
+        Op op;
+        op.kind = OP_BNECK;
+        op.mode = with_cv2 ? 1 : 0;
+        op.shortcut = shortcut;
+        op.layer = prefix + ".m." + std::to_string(i) + (with_cv2 ? " + cv2 (one launch)" : " (one launch)");
+        snprintf(op.kname, sizeof op.kname, with_cv2 ? "bneck64_b" : "bneck64_a");
+        snprintf(op.kname_one, sizeof op.kname_one, "%s", op.kname);
+        op.sub[0] = i_m1; op.sub[1] = i_m2; op.sub[2] = with_cv2 ? last : -1;
+        op.Hin = op.Hout = bH; op.Win = op.Wout = bW;
+        op.out_t = with_cv2 ? out_t : cat;
+        op.res_t = cat;
+        const double px = (double)bH * bW;
+        for (int k = 0; k < 3; k++)
+            if (op.sub[k] >= 0) { op.flops += e->ops[op.sub[k]].flops; op.w_bytes += e->ops[op.sub[k]].w_bytes; }
+        op.bytes = op.w_bytes + px * 64 * 2.0 + (with_cv2 ? px * (64.0 * n + 128.0) * 2.0 : px * 64 * 2.0);   // y_in once; + the other concat slices and the block output, or y_next
+        op.bneck = 1;
+        e->ops.push_back(op);
+        const int me = (int)e->ops.size() - 1;
+        e->ops[i_m1].bneck = me; e->ops[i_m2].bneck = me;
+        if (with_cv2) e->ops[last].bneck = me;
+    }
+    e->lazy_tensors.insert(e->tensors[cat].name);   // (a single-frame step leaves the last slice of the concat buffer and the bottleneck intermediate unwritten:
+    return IRMV_OK;                                 //  read-backs of them run the layer ops, like the fused 32-channel blocks')
+}
+
 static int add_c2f(irmv_engine *e, const std::string &prefix, SegRef s0, SegRef s1, int H, int W, int c2, int n,
                    bool shortcut, int out_t)
 {
@@ -622,6 +672,10 @@ static int add_c2f(irmv_engine *e, const std::string &prefix, SegRef s0, SegRef 
     }
     TRY(add_conv(e, prefix + ".cv2", SegRef{cat, 0, (2 + n) * c, 0}, SegRef{}, H, W, out_t, 0));
     TRY(fuse_c2f32(e, prefix, n, shortcut, cat, tmp, out_t));
+    if (c == 64) {
+        TRY(fuse_bneck64(e, prefix, n, shortcut, cat, out_t));
+        if (!e->ops.empty() && e->ops.back().kind == OP_BNECK) e->lazy_tensors.insert(e->tensors[tmp].name);
+    }
     return IRMV_OK;
 }
 
@@ -693,6 +747,7 @@ static int build_engine(irmv_engine *e)
     // for engines of TripleBuffer size, whose single-slot steps then overlap
     e->num_streams = c.num_streams > 0 ? c.num_streams : (c.num_slots <= 4 ? c.num_slots : std::min(4, std::max(2, (c.num_slots + 127) / 128)));   // batched: two graphs of up to 128 frames (round 3: with the
                                                                                                                                                    // weights-resident / multi-block kernels larger graphs win: 256 frames as 2 x 128 +6 % over 192 as 3 x 64)
+    { const char *bn = getenv("IRMV_BNECK64"); e->bneck64 = !(bn && bn[0] == '0'); }   // (read before the op list is built)
     if (const char *ns = getenv("IRMV_STREAMS")) e->num_streams = atoi(ns);
     e->num_streams = std::max(1, std::min({e->num_streams, 8, c.num_slots}));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));
@@ -1881,7 +1936,10 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         if (grouped && e->head_groups[op.group].members[0] != (int)(&op - e->ops.data())) continue;   // rides in its group's launch
         // a step skips the layers a fused kernel covers; a read-back runs only those (and the unfused form of a conv that
         // normally carries a 1x1 in its epilogue)
-        if (materialize ? !(op.fused_away || op.fuse_next >= 0) : op.fused_away) continue;
+        // single-frame steps: the 64-channel Bottlenecks ride in their OP_BNECK launch; every other step runs the layers
+        const bool one_frame = count == 1 && !materialize && !post_only && e->bneck64;
+        if (op.kind == OP_BNECK ? !one_frame : (op.bneck >= 0 && one_frame)) continue;
+        if (materialize ? !(op.fused_away || op.fuse_next >= 0 || (op.bneck >= 0 && op.kind == OP_CONV)) : op.fused_away) continue;
         hipStream_t s = e->stream;
         EvRec r{};
         r.op = (int)(&op - e->ops.data());
@@ -1938,6 +1996,27 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         }
         case OP_C2F32: {
             if (!launch_c2f32_op(e, op, first, count, s)) return fail(IRMV_ERR_ARG, "no fused C2f kernel for " + op.layer);
+            break;
+        }
+        case OP_BNECK: {
+            const Op &m1 = e->ops[op.sub[0]], &m2 = e->ops[op.sub[1]];
+            const Tensor &ct = e->tensors[op.res_t];
+            BneckArgs a{};
+            a.yin = static_cast<const half_t *>(ct.slot(first)) + m1.s0.coff; a.yin_ld = ct.C;
+            a.ynext = static_cast<half_t *>(ct.slot(first)) + m2.out_coff; a.ynext_ld = ct.C;
+            a.cat = static_cast<const half_t *>(ct.slot(first)); a.cat_ld = ct.C;
+            a.H = op.Hin; a.W = op.Win;
+            a.tiles_x = (op.Win + kBneckTile - 1) / kBneckTile; a.tiles_y = (op.Hin + kBneckTile - 1) / kBneckTile;
+            a.w_m1 = m1.w_lds[0]; a.b_m1 = m1.bias; a.w_m2 = m2.w_lds[0]; a.b_m2 = m2.bias;
+            int ks2 = 6;
+            if (op.sub[2] >= 0) {
+                const Op &c2 = e->ops[op.sub[2]];
+                const Tensor &ot = e->tensors[c2.out_t];
+                a.out = static_cast<half_t *>(ot.slot(first)) + c2.out_coff; a.out_ld = ot.C;
+                a.w_cv2 = c2.w_packed; a.b_cv2 = c2.bias;
+                ks2 = c2.ksteps;
+            }
+            if (!launch_bneck64(op.mode, ks2, op.shortcut, a, count, s)) return fail(IRMV_ERR_ARG, "no fused bottleneck kernel for " + op.layer);
             break;
         }
         case OP_DW: {

@@ -213,6 +213,26 @@ struct C2f32Args {
 size_t c2f32_lds_bytes(int mode);
 bool launch_c2f32(int mode, bool shortcut, const C2f32Args &a, int batch, hipStream_t s);
 
+// one 64-channel Bottleneck [+ the block's cv2] of a C2f block in one launch, single-frame steps (k_bneck.hip)
+constexpr int kBneckTile = 8;
+struct BneckArgs {
+    const half_t *yin;    // the Bottleneck's input: a 64-channel slice of the block's concat buffer [B][H][W][yin_ld], offset to its first channel
+    int yin_ld;
+    half_t *ynext;        // mode A: the next 64-channel slice of the concat buffer (same pixel indexing)
+    int ynext_ld;
+    const half_t *cat;    // mode B: the concat buffer from channel 0 (cv2 reads the slices in front of y_in from here)
+    int cat_ld;
+    half_t *out;          // mode B: block output [B][H][W][out_ld], 128 channels
+    int out_ld;
+    int H, W, tiles_x, tiles_y;
+    const half_t *w_m1, *w_m2;   // LDS-family nt = 1 packing [4 tiles][2 chunks][9 taps][64 lanes][8]
+    const float *b_m1, *b_m2;
+    const half_t *w_cv2;         // direct-family packing [8 tiles][k-steps][64 lanes][8]
+    const float *b_cv2;
+};
+size_t bneck64_lds_bytes(int mode, int ks2);
+bool launch_bneck64(int mode, int ks2, bool shortcut, const BneckArgs &a, int batch, hipStream_t s);   // mode 0: A (-> concat slice), 1: B (+ cv2, ks2 = 6 / 8)
+
 struct ConvArgs {
     ConvSeg s0, s1;
     int Hin, Win;       // input size at the conv's own resolution

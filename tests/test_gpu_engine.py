@@ -665,7 +665,7 @@ def test_resident_weight_kernels_are_bitwise_the_chunked_ones(blob, monkeypatch,
 @pytest.mark.parametrize("switch", ["IRMV_INLINE_COPIES=1", "IRMV_ZERO_COPY_RESULTS=0", "IRMV_SPLIT_SCAN=0", "IRMV_EMIT_SCAN=0",
                                     "IRMV_FUSED_HEAD=0", "IRMV_MERGE_HEAD0=0", "IRMV_GROUP_HEAD=0", "IRMV_NO_PF2=1", "IRMV_NO_DEEP=1",
                                     "IRMV_FRONT_FASTX=0", "IRMV_FRONT_DIRECT=0", "IRMV_FRONT_TILE8=0",
-                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1", "IRMV_NMS_CLASSWALK=0", "IRMV_NO_PF4=1", "IRMV_WRES_STAGGER=0"])
+                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1", "IRMV_NMS_CLASSWALK=0", "IRMV_NO_PF4=1", "IRMV_WRES_STAGGER=0", "IRMV_BNECK64=0"])
 def test_every_remaining_switch_is_bitwise_the_default(blob, monkeypatch, switch):
     """The environment switches that select between implementations of the same arithmetic (where the copies ride, where the
     results land, where candidates are found, which launches are merged): heads and detections of a batched step, of
@@ -781,6 +781,44 @@ def test_merged_head_first_stage_is_bitwise_the_separate_convs(blob, frame0, mon
     monkeypatch.delenv("IRMV_MERGE_HEAD0")
     with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=8) as e:      # batched engines keep the separate convs
         assert not any(st["layer"].startswith("model.22.s0.") for st in e.profile(0, 4))
+
+
+def test_single_frame_bottleneck_kernels_are_bitwise_the_layers(blob, monkeypatch):
+    """Steps of ONE frame run the 64-channel Bottlenecks of model.6 / 12 / 18 as one launch each, the block's last one together
+    with its cv2 (k_bneck.hip: 14 launches -> 4).  Same rounding points and K order as the per-layer kernels: block outputs,
+    head and detections are theirs bit for bit -- 640 net (40 x 40 maps: 25 whole tiles) and 416 net (26 x 26: partial tiles
+    on two sides), pose and bbox-only models, detect() and pipelined single-frame steps; a batched step of the same engine
+    keeps the layers and gives the same bits; read-backs of the blocks' internal tensors still work."""
+    from irmv_detection_amd import weights
+    img = frames.synthetic_frame(5)
+    for b, net in ((blob, 640), (blob, 416), (weights.synthetic_blob(0, nk=0), 640)):
+        outs = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("IRMV_BNECK64", mode)
+            with YoloEngine(None, (1280, 1024), weights_blob=b, net_size=net, num_slots=3, point_source=capi.POINTS_AUTO) as e:
+                names = [st["name"] for st in e.profile(0, 1)]
+                assert (sum(n == "bneck64_a" for n in names), sum(n == "bneck64_b" for n in names)) == ((1, 3) if mode == "1" else (0, 0)), names
+                layers = [st["layer"] for st in e.profile(0, 1)]
+                assert any(l == "model.12.m.0.cv1" for l in layers) == (mode == "0")
+                assert not any(n.startswith("bneck64") for n in (st["name"] for st in e.profile(0, 3)))   # a batched step keeps the layers
+                _load(e, 0, img)
+                e.detect(0)
+                got = [e.read_head(0).copy()] + [e.read_tap(t, 0).copy() for t in ("6", "12", "18")] + [_raw_tuple(e.read_raw(0))]
+                got += [e.read_tap(t, 0).copy() for t in ("model.6.cat", "model.12.cat", "model.18.tmp")]   # internal tensors: materialised by the layer ops
+                for s in range(3):
+                    _load(e, s, img)
+                e.submit(0, 3); e.wait()                 # the batched step (layer kernels) ...
+                got.append(e.read_head(2).copy())
+                assert np.array_equal(got[0], got[-1])   # ... equals the single-frame step of the same engine
+                e.submit(1, 1, async_upload=True); e.wait_slots(1, 1)
+                got.append(_raw_tuple(e.read_raw(1)))
+                outs.append(got)
+        for x, y in zip(*outs):
+            if isinstance(x, tuple):
+                assert x[0] == y[0] and all(np.array_equal(p, q) for p, q in zip(x[1:], y[1:])), net
+            else:
+                assert np.array_equal(x, y), net
+    monkeypatch.delenv("IRMV_BNECK64")
 
 
 def test_grouped_detect_launches_are_bitwise_the_separate_convs(blob, monkeypatch):
