@@ -161,6 +161,7 @@ struct Op {
     int Hin = 0, Win = 0, Hout = 0, Wout = 0, cin = 0, cout = 0, cout_pad = 0, ksteps = 0;
     int out_t = -1, out_coff = 0, res_t = -1, res_coff = 0;
     half_t *w_packed = nullptr;
+    half_t *w_k16 = nullptr;   // 1x1 layers with Cin = 16 and fp32 output (the keypoint branch's finals): the weights in the A layout of v_mfma_f32_16x16x16_f16 [64 lanes][4]
     half_t *w_lds[4] = {nullptr, nullptr, nullptr, nullptr};   // LDS-kernel layout for nt = 1 / 2 / 4 / 8 (eligible 3x3 layers only; nt = 8: stride-2 layers with >= 128 output channels)
     float *bias = nullptr;
     double flops = 0, bytes = 0;  // per frame (bytes: activations in + out, plus the weights)
@@ -395,6 +396,15 @@ static int pack_conv(irmv_engine *e, const LayerW &l, Op &op)
     if (rc) return rc;
     HIP_TRY(hipMemcpy(op.w_packed, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(op.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    if (l.k == 1 && l.cin == 16 && op.cfg.out_f32 && l.act == 0 && op.cout_pad == 16) {   // lane (g, r): output channel r, input channels 4 g .. 4 g + 3
+        std::vector<uint16_t> pk(64 * 4, 0);
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 4; j++)
+                if ((lane & 15) < l.cout) pk[lane * 4 + j] = l.w[(size_t)(lane & 15) * l.cin + 4 * (lane >> 4) + j];
+        int rc3 = dev_alloc(e, (void **)&op.w_k16, pk.size() * 2);
+        if (rc3) return rc3;
+        HIP_TRY(hipMemcpy(op.w_k16, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    }
     // LDS-kernel layout: [n-block][chunk of 32 ch][tap][tile in block][lane][8]
     if (l.k == 3 && l.cin % 32 == 0 && l.act == 1 && !op.cfg.out_f32) {
         const int chunks = l.cin / 32;
@@ -1027,6 +1037,9 @@ static int build_engine(irmv_engine *e)
                 if (!(fh && fh[0] == '0') && o1.cout == 64 && o1.cin % 32 == 0 && o1.pair && o1.res_t < 0 && o1.cfg.stride == 1 &&
                     o2.cin == 64 && o2.ksteps == 2 && o2.cfg.ks == 1 && o2.cfg.out_f32 && o2.cfg.act == 0 && (o2.cout_pad == 16 || o2.cout_pad == 64))
                     e->ops[i1].fuse_next = i2;
+                // ... and the keypoint branch's 16 -> nk final in the epilogue of the Cin = 16 direct kernel (one 16x16x16 MFMA per 16 pixels)
+                if (!(fh && fh[0] == '0') && o1.cfg.cin16 && o1.cout_pad == 16 && !o1.pair && o1.res_t < 0 && o1.cfg.stride == 1 && o1.cfg.act == 1 && o2.w_k16)
+                    e->ops[i1].fuse_next = i2;
             }
         }
 
@@ -1352,6 +1365,7 @@ static int lds_index(int nt) { return nt == 8 ? 3 : (nt == 4 ? 2 : (nt == 2 ? 1 
 static bool run_conv(const Op &op, const ConvCfg &c, const ConvArgs &a, int count, hipStream_t s)
 {
     const int li = lds_index(c.nt);
+    if (op.w_k16) return launch_conv_k16(a, s);   // the keypoint finals: one kernel, whatever the tile table says (same bits as their fused form)
     if (c.pw) return launch_conv_pw(c, a, s);
     if (c.wr) return c.lds && op.w_lds[2] && launch_conv_wres(c.ipw, a, op.w_lds[2], count, s, c.pp);
     if (c.lds) return op.w_lds[li] && launch_conv_lds(c.stride, c.mt, c.nt, c.ipw, a, op.w_lds[li], count, s, c.pf4 ? 2 : (c.pf2 ? 1 : 0), c.cm, c.w8);
@@ -1405,8 +1419,9 @@ static int autotune_convs(irmv_engine *e)
         if (op.kind != OP_CONV) continue;
         for (int pass = 0; pass < (counts[0] > 1 ? 2 : 1); pass++) {
             ConvArgs a;
-            bool want_fuse = op.fuse_next >= 0;
-            fill_conv_args(e, op, 0, counts[pass], a, want_fuse);
+            const bool fuse_k16 = op.fuse_next >= 0 && op.cfg.cin16;   // the keypoint final in the direct kernel's epilogue: any pixel tile (nt = 1 is the layer's only one)
+            bool want_fuse = op.fuse_next >= 0 && !fuse_k16;
+            fill_conv_args(e, op, 0, counts[pass], a, want_fuse || fuse_k16);
             if (want_fuse) {   // the fused epilogue needs an LDS-family tile that owns all 64 channels (nt = 4)
                 bool f_ok = false;
                 for (int mt = 1; mt <= 4 && !f_ok; mt *= 2) f_ok = !only_direct && op.w_lds[2] && conv_lds_bytes(a, op.cfg.stride, mt, 4, nullptr) > 0;
@@ -1669,7 +1684,8 @@ static void finalize_head_fusion(irmv_engine *e)
     } tail{e};
     for (Op &op : e->ops) {
         if (op.fuse_next < 0) continue;
-        const bool ok = op.cfg.lds && op.cfg.nt == 4 && op.cfg_one.lds && op.cfg_one.nt == 4;
+        const bool k16 = op.cfg.cin16 && !op.cfg.lds && !op.cfg_one.lds && !op.cfg.deep && !op.cfg_one.deep && op.cfg.nt == 1 && op.cfg_one.nt == 1 && e->ops[op.fuse_next].w_k16;
+        const bool ok = k16 || (op.cfg.lds && op.cfg.nt == 4 && op.cfg_one.lds && op.cfg_one.nt == 4);
         if (!ok) { op.fuse_next = -1; continue; }
         e->ops[op.fuse_next].fused_away = true;
         e->lazy_tensors.insert(e->tensors[op.out_t].name);
@@ -1796,7 +1812,9 @@ static int build_head_groups(irmv_engine *e)
     if (kpt) {
         const size_t before = e->head_groups.size();
         try_group(g3, 1, {1}, "head_kpt1");
-        if (e->head_groups.size() > before) try_group(g4, 1, {1}, "head_kpt2");
+        bool k16 = false;   // (finals on the 16x16x16 MFMA are fused into the convs in front of them, or run launch_conv_k16: the grouped direct kernel would give other bits)
+        for (int i : g4) k16 = k16 || i < 0 || e->ops[i].w_k16 != nullptr;
+        if (e->head_groups.size() > before && !k16) try_group(g4, 1, {1}, "head_kpt2");
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
     return IRMV_OK;
@@ -1843,12 +1861,13 @@ static void fill_conv_args(const irmv_engine *e, const Op &op, int first, int co
     if (fused && op.fuse_next >= 0) {
         const Op &o2 = e->ops[op.fuse_next];
         const Tensor &t2 = e->tensors[o2.out_t];
-        a.w2 = o2.w_packed;
+        a.w2 = op.cfg.cin16 ? o2.w_k16 : o2.w_packed;
         a.bias2 = o2.bias;
         a.out2 = static_cast<float *>(t2.slot(first)) + o2.out_coff;
         a.out2_ld = t2.C;
         a.n2 = o2.cout_pad / 16;
     }
+    if (op.w_k16) a.w2 = op.w_k16;   // a Cin = 16 final as its own launch (launch_conv_k16)
 }
 
 static LightArgs light_args(const irmv_engine *e, int first)

@@ -55,6 +55,13 @@ __device__ __forceinline__ half4 silu_pack4(float y0, float y1, float y2, float 
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(half4, (u32x2_t){silu_pack2(y0, y1), silu_pack2(y2, y3)});
 }
+// An MFMA that takes a SiLU output as its A / B operand straight from the registers (the fused finals of k_conv.hip): the
+// hardware needs two wait states between a vector-ALU write of a VGPR and an MFMA's read of it, and the compiler, which
+// inserts them for instructions it knows, does not look inside the inline asm above -- with the last v_fma_mixhi_f16 one
+// instruction in front of the MFMA the matrix pipe read the register's OLD value (round 5: the keypoint final came out
+// wrong in 60 % of its outputs).  These ties put an `s_nop 1` between the asm's writes and whatever reads the value next.
+__device__ __forceinline__ void mfma_operand_fence(half4 &x) { asm volatile("s_nop 1" : "+v"(x)); }
+__device__ __forceinline__ void mfma_operand_fence(half8 &x, half8 &y) { asm volatile("s_nop 1" : "+v"(x), "+v"(y)); }
 // shortcut layers: half(round32(y * sigma(y)) + res), every intermediate rounded where it is written
 __device__ __forceinline__ half_t silu_add_res(float y, float res)
 {
@@ -250,6 +257,7 @@ struct ConvArgs {
     int pair;           // weight rows packed with the paired-tile channel permutation
     // optional trailing 1x1 conv fused into the epilogue of the LDS 3x3 kernel (Detect-head finals: bias only, fp32
     // out): this conv's activated fp16 output never leaves the registers.  n2 = 16-row tiles of the 1x1 (0 = none).
+    // (Cin = 16 direct kernel, keypoint branch: w2 = the 16 -> nk final in the 16x16x16 MFMA's A layout [64 lanes][4], n2 = 1.)
     const half_t *w2;   // direct-family packing of the 1x1 [tile][k-step][64][8], Cin = this conv's 64 channels
     const float *bias2;
     float *out2;
@@ -302,6 +310,7 @@ bool conv_pw_eligible(const ConvCfg &cfg, const ConvArgs &a);
 // 1x1 fp32 bias-only; mt = nt = 1).  false: some member has no such tile.
 bool launch_conv_lds_multi(int nt, const ConvArgs *a, const half_t *const *wl, int n, int batch, hipStream_t s);
 bool launch_conv_direct_multi(const ConvCfg &cfg, const ConvArgs *a, int n, hipStream_t s);
+bool launch_conv_k16(const ConvArgs &a, hipStream_t s);   // 1x1, Cin = 16 -> <= 16 channels, bias only, fp32 out: a.w2 = weights in the 16x16x16 MFMA's A layout
 bool launch_conv_pw(const ConvCfg &cfg, const ConvArgs &a, hipStream_t s);   // cfg.ipw = NBW: 64-channel output blocks per workgroup (1: the single-block kernel)
 size_t conv_pw_lds_bytes(const ConvArgs &a, int nbw);                        // NBW = 2 / 4: LDS of the multi-block form, 0 = not offered
 // LDS-staged 3x3 family (k_conv.hip): wl = weights packed [n-block][chunk 32][tap][tile][lane][8] for this nt

@@ -77,6 +77,19 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, int wg_x, int 
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) acc[mt][nt] = ACT == 1 ? bs[nt] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Cin = 16 layers with ONE 16-channel output tile (the keypoint branch's second 3x3): the branch's final 1x1 (16 -> nk, bias
+    // only, fp32 out) can ride in the epilogue (a.n2 = 1) -- the lane's four activated outputs, channels 4 g .. 4 g + 3 of its
+    // pixel, ARE the B fragment of v_mfma_f32_16x16x16_f16 over those 16 channels.  Its operands are fetched here, with the
+    // first k-steps (fetched in the epilogue they would cost a memory round trip behind the main loop).
+    constexpr bool K16_FUSE = CIN16 && NT == 1 && ACT == 1 && !OUT_F32;
+    half4 w2f = (half4){0, 0, 0, 0};
+    f32x4 b2f = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (K16_FUSE) {
+        if (a.n2 > 0) {
+            w2f = *reinterpret_cast<const half4 *>(a.w2 + lane * 4);
+            b2f = *reinterpret_cast<const f32x4 *>(a.bias2 + g * 4);
+        }
+    }
 
     const half8 *wp = reinterpret_cast<const half8 *>(a.w) + (size_t)nt0 * a.ksteps * 64 + lane;
     const int H0 = a.Hin >> a.s0.shift, W0 = a.Win >> a.s0.shift;
@@ -177,6 +190,19 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, int wg_x, int 
     // D layout of 16x16x32: col = lane & 15 (pixel), row = (lane >> 4) * 4 + reg (cout row of the tile).
     // a.pair: the host packed the weight rows so that tiles (2u, 2u+1) interleave in groups of 4
     // channels: lane g of tile t holds channels (t>>1)*32 + g*8 + (t&1)*4 + [0,4).
+    if constexpr (K16_FUSE) {
+        if (a.n2 > 0) {   // (kernel-uniform) fused final 1x1: the MFMA runs with every lane -- its A rows live in all 64 -- and only the stores are masked
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                half4 o = silu_pack4(acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
+                mfma_operand_fence(o);   // (VALU write -> MFMA read: two wait states the compiler cannot see through the inline asm)
+                const f32x4 c2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w2f, o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 v2 = (f32x4){c2[0] * kActUnscale + b2f[0], c2[1] * kActUnscale + b2f[1], c2[2] * kActUnscale + b2f[2], c2[3] * kActUnscale + b2f[3]};   // (the 1x1's input carries the activation scale)
+                if (mv[mt]) *reinterpret_cast<f32x4 *>(a.out2 + (size_t)mm[mt] * a.out2_ld + g * 4) = v2;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
         if (!mv[mt]) continue;
@@ -323,6 +349,31 @@ bool launch_conv(const ConvCfg &c, const ConvArgs &a, hipStream_t s)
     IRMV_CASE(1, 1, false, 0, true)    // 1x1 head finals: bias only, fp32 out
 #undef IRMV_CASE
     return false;
+}
+
+// The keypoint branch's final 1x1 (16 -> nk <= 16, bias only, fp32 out) as its own launch: ONE v_mfma_f32_16x16x16_f16 per 16
+// pixels -- the instruction, operands and rounding of the fused form above (conv_mfma_body, K16_FUSE), so that the fused
+// and the unfused head agree bit for bit.  a.w2 = the layer's weights in that instruction's A layout (lane (g, r): output
+// channel r, input channels 4 g .. 4 g + 3), a.bias = its bias; input at the layer's own resolution, one segment.
+__global__ __launch_bounds__(256) void conv1x1_k16_f32_kernel(ConvArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int m = (blockIdx.x * 4 + wave) * 16 + r;
+    const bool mv = m < a.M;
+    const half4 w = *reinterpret_cast<const half4 *>(a.w2 + lane * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + g * 4);
+    const half4 x = *reinterpret_cast<const half4 *>(a.s0.p + (size_t)(mv ? m : 0) * a.s0.ld + g * 4);
+    const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x16f16(w, x, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    if (mv) *reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + (size_t)m * a.out_ld + g * 4) =
+        (f32x4){c[0] * kActUnscale + b[0], c[1] * kActUnscale + b[1], c[2] * kActUnscale + b[2], c[3] * kActUnscale + b[3]};
+}
+
+bool launch_conv_k16(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin != 16 || a.cout_pad != 16 || !a.w2 || a.s1.C != 0 || a.s0.shift != 0) return false;
+    hipLaunchKernelGGL(conv1x1_k16_f32_kernel, dim3(((a.M + 15) / 16 + 3) / 4), dim3(256), 0, s, a);
+    return true;
 }
 
 bool launch_conv_direct_multi(const ConvCfg &c, const ConvArgs *a, int n, hipStream_t s)
@@ -1015,6 +1066,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const ConvArgs &a, const half_t
                         if constexpr (N2 == 0) *reinterpret_cast<half8 *>(static_cast<half_t *>(a.out) + m * a.out_ld + c0) = ov[u];
                     }
                     if constexpr (N2 > 0) {
+                        mfma_operand_fence(ov[0], ov[1]);   // (irmv_common.hpp: the MFMAs below read what inline asm has just written)
                         // With the paired-tile packing lane (g, r) now holds channels u*32 + 8g + [0, 8) of pixel r: exactly the
                         // B fragment of k-step u of a 1x1 conv over these 64 channels.  Same operands, same k order as the
                         // stand-alone 1x1 kernel reading this tensor back from memory.
