@@ -509,6 +509,10 @@ def main():
                 leng.wait_slots(i % 3, 1)
             leng.wait()
             pipe[depth + 1] = round(n_pipe / (time.perf_counter() - t1), 1)
+        late["single_frame_launch"] = dict(form=getattr(leng, "sync_launch", "graph"),
+                                           note="how a synchronous detect() reaches the GPU on this box: one hipGraph replay (upload = its first node) or the same launches issued one by "
+                                                "one behind the upload; the engine times both at creation and keeps the faster (include/irmv_hip.h irmv_engine_sync_launch; same kernels, same "
+                                                "bits); pipelined and batched steps are always graph replays")
         late["fps_single_frames_in_flight"] = {"1": round(1e3 / late["latency_ms_single_frame_h2d_inclusive"], 1), "2": pipe[2], "3": pipe[3],
                                                 "note": "one frame per captured step, frames from pinned host slots (H2D inclusive), three slots, a compute stream per slot"}
         leng.close()

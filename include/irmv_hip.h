@@ -149,6 +149,8 @@ void irmv_engine_destroy(irmv_engine *e);
 int irmv_engine_num_slots(const irmv_engine *e);
 int irmv_engine_max_det(const irmv_engine *e);
 int irmv_engine_num_streams(const irmv_engine *e);
+int irmv_engine_sync_launch(const irmv_engine *e);   /* how a synchronous single-frame step is launched on this box: 0 = one hipGraph replay, 1 = kernel by kernel
+                                                        behind the upload (same kernels, same bits; timed at creation, IRMV_SYNC_LAUNCH=graph|eager forces) */
 
 /* ---- NUMA placement of the frame hand-off (multi-GPU nodes; the reference is single-device, test/yolo_test.cpp:16) ----
  * An engine allocates and first-touches its pinned frame slots on the host NUMA node closest to its device

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("irmv_engine_num_slots", C.c_int, [_P]),
     ("irmv_engine_max_det", C.c_int, [_P]),
     ("irmv_engine_num_streams", C.c_int, [_P]),
+    ("irmv_engine_sync_launch", C.c_int, [_P]),
     ("irmv_engine_numa_node", C.c_int, [_P]),
     ("irmv_engine_numa_placed", C.c_int, [_P]),
     ("irmv_numa_device_node", C.c_int, [C.c_int, C.POINTER(C.c_int)]),

@@ -227,8 +227,14 @@ struct irmv_engine {
     std::map<std::pair<int, int>, SlotGroup> groups;   // (first, count) -> events of that group's last submit
     std::vector<SlotGroup *> slot_owner;               // per slot: the group whose submit touched it last
     bool inline_copies = false;                        // IRMV_INLINE_COPIES=1: round-1 behaviour, copies on the compute stream
-    bool graph_upload = true;                          // uploads that ride the compute stream are a node of the step's graph (IRMV_GRAPH_UPLOAD=0: a separate copy)
+    bool graph_upload = true;                          // uploads that ride the compute stream are a node of the step's graph (IRMV_GRAPH_UPLOAD=0: a separate launch in front of it; measured
+                                                       // again in round 5 with the upload kernel: 0.3365 - 0.3438 ms against 0.335 - 0.336 as the first node: no hiding of the graph's launch cost)
     uint8_t *src_host = nullptr;  // pinned [S][frame]
+    int sync_launch = 0;               // how a synchronous single-frame step (detect()) reaches the GPU: 0 = one hipGraph replay (upload = its first node), 1 = launched
+                                       // kernel by kernel behind the upload; chosen by timing at creation (choose_sync_launch), IRMV_SYNC_LAUNCH=graph|eager forces
+    hipStream_t enq_stream = nullptr;  // (set around an eager step: the stream enqueue_step launches on instead of `stream`)
+    uint8_t *src_host_dev = nullptr;   // the same memory through the device's mapping (the upload kernel reads it: launch_upload_frames)
+    int upload_kernel_blocks = 256;    // 0: synchronous single-frame uploads ride the copy engine like every other upload (IRMV_UPLOAD_KERNEL=0)
     uint8_t *src_dev = nullptr;   // [S][frame]
     uint8_t *rot_dev = nullptr;   // [frame]
     AxisTap *tap_x = nullptr, *tap_y = nullptr;
@@ -778,6 +784,8 @@ static int build_engine(irmv_engine *e)
         HIP_TRY(hipHostMalloc((void **)&e->src_host, e->frame_bytes * S, user ? (hipHostMallocDefault | hipHostMallocNumaUser) : hipHostMallocDefault));
         log_range(e, "pinned src_host", e->src_host, e->frame_bytes * S);
         memset(e->src_host, 0, e->frame_bytes * S);   // first touch, by the bound thread
+        if (hipHostGetDevicePointer((void **)&e->src_host_dev, e->src_host, 0) != hipSuccess) { e->src_host_dev = nullptr; (void)hipGetLastError(); }
+        if (const char *uk = getenv("IRMV_UPLOAD_KERNEL")) e->upload_kernel_blocks = atoi(uk);
         e->numa_placed = user && scope.bound();
     }
     TRY(dev_alloc(e, (void **)&e->src_dev, e->frame_bytes * S));
@@ -1244,6 +1252,31 @@ extern "C" void irmv_engine_cfg_default(irmv_engine_cfg *cfg)
     cfg->armor_min_large_center_distance = 3.2; cfg->armor_max_large_center_distance = 5.5;
 }
 
+// Which launch form serves detect() on this box: both timed on slot 0 (whatever its pinned slot holds: zeros at creation), the
+// eager one kept only if it is at least 1 % faster.  IRMV_SYNC_LAUNCH=graph|eager skips the timing.
+extern "C" int irmv_engine_submit(irmv_engine *e, int first, int count, uint32_t flags);
+extern "C" int irmv_engine_wait_slots(irmv_engine *e, int first, int count);
+static int choose_sync_launch(irmv_engine *e)
+{
+    if (const char *v = getenv("IRMV_SYNC_LAUNCH")) {
+        if (v[0] == 'e' || v[0] == 'g') { e->sync_launch = v[0] == 'e' ? 1 : 0; return IRMV_OK; }   // (anything else, e.g. "auto": time it)
+    }
+    double t[2] = {0.0, 0.0};
+    for (int round = 0; round < 2; round++)
+        for (int mode = 0; mode < 2; mode++) {
+            e->sync_launch = mode;
+            for (int i = 0; i < 24; i++) {
+                const auto t0 = std::chrono::high_resolution_clock::now();
+                TRY(irmv_engine_submit(e, 0, 1, IRMV_SUBMIT_H2D));
+                TRY(irmv_engine_wait_slots(e, 0, 1));
+                if (i >= 8) t[mode] += std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count();
+            }
+        }
+    e->sync_launch = t[1] < 0.99 * t[0] ? 1 : 0;
+    if (getenv("IRMV_AUTOTUNE_VERBOSE")) fprintf(stderr, "[irmv] synchronous single-frame step: graph replay %.1f us, eager launches %.1f us -> %s\n", t[0] / 32, t[1] / 32, e->sync_launch ? "eager" : "graph");
+    return IRMV_OK;
+}
+
 extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
 {
     if (!cfg || !out) return fail(IRMV_ERR_ARG, "cfg/out is null");
@@ -1279,9 +1312,13 @@ extern "C" int irmv_engine_create(const irmv_engine_cfg *cfg, irmv_engine **out)
     finalize_head_fusion(e.get());
     rc = build_head_groups(e.get());
     if (rc) return rc;
+    rc = choose_sync_launch(e.get());
+    if (rc) return rc;
     *out = e.release();
     return IRMV_OK;
 }
+
+extern "C" int irmv_engine_sync_launch(const irmv_engine *e) { return e ? e->sync_launch : 0; }
 
 extern "C" void irmv_engine_destroy(irmv_engine *e) { delete e; }
 extern "C" int irmv_engine_num_slots(const irmv_engine *e) { return e ? e->cfg.num_slots : 0; }
@@ -1959,7 +1996,7 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         const bool one_frame = count == 1 && !materialize && !post_only && e->bneck64;
         if (op.kind == OP_BNECK ? !one_frame : (op.bneck >= 0 && one_frame)) continue;
         if (materialize ? !(op.fused_away || op.fuse_next >= 0 || (op.bneck >= 0 && op.kind == OP_CONV)) : op.fused_away) continue;
-        hipStream_t s = e->stream;
+        hipStream_t s = e->enq_stream ? e->enq_stream : e->stream;
         EvRec r{};
         r.op = (int)(&op - e->ops.data());
         if (ev) {
@@ -2138,7 +2175,13 @@ static int get_graph(irmv_engine *e, int first, int count, uint32_t flags, bool 
     hipGraph_t g = nullptr;
     HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     int rc = IRMV_OK;
-    if (flags & 0x10000000u) rc = copy_in(e, first, count, e->stream);   // the frames' upload as the graph's first node (synchronous single-stream submits)
+    if (flags & 0x10000000u) {   // the frames' upload as the graph's first node (synchronous single-stream submits): one or two frames as a kernel
+        const size_t off = (size_t)first * e->frame_bytes, bytes = e->frame_bytes * count;
+        if (count <= 2 && e->upload_kernel_blocks > 0 && e->src_host_dev && off % 16 == 0 && bytes % 16 == 0)
+            launch_upload_frames(e->src_host_dev + off, e->src_dev + off, bytes, e->upload_kernel_blocks, e->stream);
+        else
+            rc = copy_in(e, first, count, e->stream);
+    }
     if (!rc) rc = enqueue_step(e, first, count, (flags & ~0x10000000u) | 0x40000000u, post_only, nullptr);
     hipError_t ce = hipStreamEndCapture(e->stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -2183,9 +2226,14 @@ static int submit_group(irmv_engine *e, int f, int c, uint32_t flags, hipStream_
     // An upload that rides the compute stream anyway (the synchronous detect()) is captured INTO the step's graph: one
     // submission instead of two, and the copy -> first kernel hand-over is the graph's own (IRMV_GRAPH_UPLOAD=0: a separate
     // hipMemcpyAsync in front of the graph, as before; same bits)
-    const bool graph_up = (flags & IRMV_SUBMIT_H2D) && !async_up && e->graph_upload;
-    hipGraphExec_t ge;
-    TRY(get_graph(e, f, c, graph_up ? 0x10000000u : 0u, false, &ge));
+    // A synchronous single-frame step (the reference's detect(), src/yolo_engine.cpp:153-177) has two launch forms with the same
+    // kernels and the same bits: ONE hipGraph replay, or its 41 launches issued one by one behind the upload (round 5: a graph
+    // replay spends ~10 us of host work before its first packet reaches the GPU, a direct launch ~4; with the 70 us upload in
+    // front the host stays far ahead of the GPU: 0.339 -> 0.331 ms per 1280 x 1024 frame).  Every other step is a graph replay.
+    const bool eager = e->sync_launch == 1 && c == 1 && (flags & IRMV_SUBMIT_H2D) && !async_up;
+    const bool graph_up = (flags & IRMV_SUBMIT_H2D) && !async_up && e->graph_upload && !eager;
+    hipGraphExec_t ge = nullptr;
+    if (!eager) TRY(get_graph(e, f, c, graph_up ? 0x10000000u : 0u, false, &ge));
     SlotGroup *g;
     TRY(group_of(e, f, c, &g));
     hipStream_t up = async_up ? e->h2d_stream : st;
@@ -2207,10 +2255,22 @@ static int submit_group(irmv_engine *e, int f, int c, uint32_t flags, hipStream_
             HIP_TRY(hipEventRecord(g->h2d, up));
             HIP_TRY(hipStreamWaitEvent(st, g->h2d, 0));
         } else if (!graph_up) {
-            TRY(copy_in(e, f, c, st));
+            // (an eager step, or IRMV_GRAPH_UPLOAD=0)  One or two frames travel as a KERNEL (k_pre.hip upload_frame_kernel), larger groups on the copy engine.
+            const size_t off = (size_t)f * e->frame_bytes, bytes = e->frame_bytes * c;
+            if (c <= 2 && e->upload_kernel_blocks > 0 && e->src_host_dev && off % 16 == 0 && bytes % 16 == 0)
+                launch_upload_frames(e->src_host_dev + off, e->src_dev + off, bytes, e->upload_kernel_blocks, st);
+            else
+                TRY(copy_in(e, f, c, st));
         }
     }
-    HIP_TRY(hipGraphLaunch(ge, st));
+    if (eager) {
+        e->enq_stream = st;
+        const int rc = enqueue_step(e, f, c, 0, false, nullptr);
+        e->enq_stream = nullptr;
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipGraphLaunch(ge, st));
+    }
     TRY(copy_out(e, f, c, st));
     HIP_TRY(hipEventRecord(g->out, st));
     g->in_flight = true;

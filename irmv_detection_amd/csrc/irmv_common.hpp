@@ -126,6 +126,7 @@ struct PreArgs {
 };
 void launch_preprocess(const PreArgs &a, int batch, hipStream_t s);
 void launch_rotate180(const uint8_t *src, uint8_t *dst, int sw, int sh, hipStream_t s);
+void launch_upload_frames(const uint8_t *src_host_mapped, uint8_t *dst, size_t bytes, int blocks, hipStream_t s);   // bytes % 16 == 0, both pointers 16-byte aligned
 
 // model.0.conv: 3x3 s2, 3(+1 pad) -> 16, SiLU
 struct Conv0Args {

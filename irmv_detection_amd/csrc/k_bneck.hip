@@ -62,45 +62,56 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs a)
     // channels of output tile t held by this lane (paired-tile packing, k_conv.hip): (t >> 1) * 32 + g * 8 + (t & 1) * 4 + [0, 4)
     const int ch3 = (n >> 1) * 32 + g * 8 + (n & 1) * 4, ch4 = (wave >> 1) * 32 + g * 8 + (wave & 1) * 4;
 
-    // ---- every weight fragment of this wave, and the biases of its channels: requested before anything else ----
+    // ---- every load of the launch is requested up front, in the order the phases need the data: the input region (phase 0
+    // waits for it alone), then the weight fragments of m.cv1, m.cv2 and cv2.  The memory counter is in-order, so each
+    // phase waits only for what was requested before ITS operands: m.cv2's and cv2's 26 fragments per wave keep streaming under
+    // phase 0's LDS stores, the first barrier and m.cv1's MFMAs (the scheduling barriers pin the request order; left alone the
+    // compiler issued one input load last and phase 0 then waited for every weight of the launch) ----
+    constexpr int NP1 = (B1N * 8 + 511) / 512;
+    u32x4 v[NP1], x[NEXTRA > 0 ? NEXTRA : 1];
+#pragma unroll
+    for (int i = 0; i < NP1; i++) {
+        const int e = tid + i * 512, px = e >> 3, q = e & 7;
+        const int ly = px / B1W, lx = px - ly * B1W;
+        const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+        const bool in = e < B1N * 8 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        v[i] = ld16g(a.yin + ((size_t)(b * H + (in ? gy : 0)) * W + (in ? gx : 0)) * a.yin_ld + q * 8);
+    }
+    const int tpx = tid >> 3, tq = tid & 7;                  // (512 pieces per tile plane: one per thread)
+    const int tgy = oy0 + (tpx >> 3), tgx = ox0 + (tpx & 7);
+    const bool tin = tgy < H && tgx < W;
+    if constexpr (NEXTRA > 0) {
+#pragma unroll
+        for (int j = 0; j < NEXTRA; j++)
+            x[j] = ld16g(a.cat + ((size_t)(b * H + (tin ? tgy : 0)) * W + (tin ? tgx : 0)) * a.cat_ld + j * 64 + tq * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     half8 W1[18], W2[18], W3[MODE == 1 ? KS2 : 1];
+    const f32x4 b1 = *reinterpret_cast<const f32x4 *>(a.b_m1 + ch3);
     {
         const half8 *w1 = reinterpret_cast<const half8 *>(a.w_m1) + (size_t)n * 18 * 64 + lane;   // nt = 1 packing: [tile][chunk][tap][lane]
-        const half8 *w2 = reinterpret_cast<const half8 *>(a.w_m2) + (size_t)n * 18 * 64 + lane;
 #pragma unroll
         for (int s = 0; s < 18; s++) W1[s] = w1[s * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b_m2 + ch3);
+    {
+        const half8 *w2 = reinterpret_cast<const half8 *>(a.w_m2) + (size_t)n * 18 * 64 + lane;
 #pragma unroll
         for (int s = 0; s < 18; s++) W2[s] = w2[s * 64];
-        if constexpr (MODE == 1) {
-            const half8 *w3 = reinterpret_cast<const half8 *>(a.w_cv2) + (size_t)wave * KS2 * 64 + lane;   // direct packing: [tile][k-step][lane]
-#pragma unroll
-            for (int ks = 0; ks < KS2; ks++) W3[ks] = w3[ks * 64];
-        }
     }
-    const f32x4 b1 = *reinterpret_cast<const f32x4 *>(a.b_m1 + ch3), b2 = *reinterpret_cast<const f32x4 *>(a.b_m2 + ch3);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 b3 = b1;
-    if constexpr (MODE == 1) b3 = *reinterpret_cast<const f32x4 *>(a.b_cv2 + ch4);
+    if constexpr (MODE == 1) {
+        b3 = *reinterpret_cast<const f32x4 *>(a.b_cv2 + ch4);
+        const half8 *w3 = reinterpret_cast<const half8 *>(a.w_cv2) + (size_t)wave * KS2 * 64 + lane;   // direct packing: [tile][k-step][lane]
+#pragma unroll
+        for (int ks = 0; ks < KS2; ks++) W3[ks] = w3[ks * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- 0: y_in with a 2-pixel halo (and, mode B, the tile's y0 [, y1]) -> LDS; all loads issued before the first store ----
+    // ---- 0: y_in with a 2-pixel halo (and, mode B, the tile's y0 [, y1]) -> LDS ----
     {
-        constexpr int NP1 = (B1N * 8 + 511) / 512;
-        u32x4 v[NP1], x[NEXTRA > 0 ? NEXTRA : 1];
-#pragma unroll
-        for (int i = 0; i < NP1; i++) {
-            const int e = tid + i * 512, px = e >> 3, q = e & 7;
-            const int ly = px / B1W, lx = px - ly * B1W;
-            const int gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            const bool in = e < B1N * 8 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            v[i] = ld16g(a.yin + ((size_t)(b * H + (in ? gy : 0)) * W + (in ? gx : 0)) * a.yin_ld + q * 8);
-        }
-        const int tpx = tid >> 3, tq = tid & 7;                  // (512 pieces per tile plane: one per thread)
-        const int tgy = oy0 + (tpx >> 3), tgx = ox0 + (tpx & 7);
-        const bool tin = tgy < H && tgx < W;
-        if constexpr (NEXTRA > 0) {
-#pragma unroll
-            for (int j = 0; j < NEXTRA; j++)
-                x[j] = ld16g(a.cat + ((size_t)(b * H + (tin ? tgy : 0)) * W + (tin ? tgx : 0)) * a.cat_ld + j * 64 + tq * 8);
-        }
 #pragma unroll
         for (int i = 0; i < NP1; i++) {
             const int e = tid + i * 512, px = e >> 3, q = e & 7;

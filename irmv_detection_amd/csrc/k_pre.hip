@@ -88,6 +88,22 @@ __global__ __launch_bounds__(256) void rotate180_kernel(const uint8_t *src, uint
     }
 }
 
+// A frame's way from its pinned host slot into HBM as a KERNEL (one 16-byte load per lane straight out of the mapped host
+// memory, 256 workgroups): for ONE 3.93 MB frame the copy engine's hipMemcpyAsync costs 77 - 103 us by box (38 - 51 GB/s: a fixed
+// start-up of 10 - 30 us on top of the link time), the kernel 11 us less (scripts/probes/hostread_probe.cpp: 102.9 -> 91.5 us;
+// from 60 MB up both sit at the link's 57 GB/s).  Used where the upload is the first node of a synchronous single-frame step
+// (the reference's detect(), src/yolo_engine.cpp:153-177); batched and pipelined uploads stay on the copy engine, which
+// runs beside the compute kernels.
+__global__ __launch_bounds__(256) void upload_frame_kernel(const u32x4_t *src, u32x4_t *dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+void launch_upload_frames(const uint8_t *src_host_mapped, uint8_t *dst, size_t bytes, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(upload_frame_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const u32x4_t *>(src_host_mapped), reinterpret_cast<u32x4_t *>(dst), bytes / 16);
+}
+
 void launch_rotate180(const uint8_t *src, uint8_t *dst, int sw, int sh, hipStream_t s)
 {
     hipLaunchKernelGGL(rotate180_kernel, dim3(2048), dim3(256), 0, s, src, dst, sw, sh);

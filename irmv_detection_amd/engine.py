@@ -139,6 +139,7 @@ class YoloEngine:
         self.max_det = max_det
         self.enable_profiling = enable_profiling
         self.num_streams = L.irmv_engine_num_streams(self._h)
+        self.sync_launch = "eager" if (hasattr(L, "irmv_engine_sync_launch") and L.irmv_engine_sync_launch(self._h) == 1) else "graph"   # how detect() reaches the GPU on this box (include/irmv_hip.h)
         has_numa = hasattr(L, "irmv_engine_numa_node")               # (absent only in an older build loaded through IRMV_LIB_PATH)
         self.numa_node = L.irmv_engine_numa_node(self._h) if has_numa else -1            # host NUMA node closest to the device (-1 unknown)
         self.numa_placed = bool(L.irmv_engine_numa_placed(self._h)) if has_numa else False  # the pinned frame slots were allocated / first touched there
