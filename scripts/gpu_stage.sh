@@ -55,7 +55,7 @@ profiles) # everything the round's profiles/ are made of, one tile table for all
          unset IRMV_TUNE_CACHE
          run bench4 600 python3 bench.py --model shufflenet --net 416 --int8 --steps 100 --warmup 10   # BASELINE configs[4], its own tiles
          grep '^{' $O/bench4.log | tail -1 > $O/bench4.json ;;
-stats1)  export IRMV_TUNE_CACHE=$R/profiles/r04_tune_cache.txt   # single-stream eager trace with the committed tile table
+stats1)  export IRMV_TUNE_CACHE=$R/profiles/r05_tune_cache.txt   # single-stream eager trace with the committed tile table
          cd /tmp; export TMPDIR=/tmp
          IRMV_STREAMS=1 run prof_stats1 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats1 -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 20
          cd $R
