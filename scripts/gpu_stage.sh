@@ -36,6 +36,8 @@ profiles) # everything the round's profiles/ are made of, one tile table for all
          run bench 700 python3 bench.py
          grep '^{' $O/bench.log | tail -1 > $O/bench.json
          cd /tmp; export TMPDIR=/tmp
+         export IRMV_SYNC_LAUNCH=graph   # the profiled passes: no timing of the two single-frame launch forms at engine creation (96 single-frame steps whose
+                                         # small launches would be averaged into the batched kernels' rows: same symbol names)
          IRMV_BENCH_SKIP=latency,h2d run prof_stats 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline
          IRMV_STREAMS=1 run pmc_f 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
          IRMV_STREAMS=1 run pmc_w 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/scripts/prof_step.py --mode eager --frames-per-step 128 --steps 2
@@ -52,7 +54,7 @@ profiles) # everything the round's profiles/ are made of, one tile table for all
          cd $R
          cp $O/prof_stats1/*/*_kernel_stats.csv $O/kernel_stats_single_stream.csv 2>/dev/null
          rm -rf $O/prof_stats1 $O/prof_stats $O/pmc_f $O/pmc_w $O/pmc_a $O/pmc_b     # raw traces: tens of MB; the reductions above are what is kept
-         unset IRMV_TUNE_CACHE
+         unset IRMV_TUNE_CACHE IRMV_SYNC_LAUNCH
          run bench4 600 python3 bench.py --model shufflenet --net 416 --int8 --steps 100 --warmup 10   # BASELINE configs[4], its own tiles
          grep '^{' $O/bench4.log | tail -1 > $O/bench4.json ;;
 stats1)  export IRMV_TUNE_CACHE=$R/profiles/r05_tune_cache.txt   # single-stream eager trace with the committed tile table
