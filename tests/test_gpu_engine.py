@@ -933,6 +933,28 @@ def test_benchmarked_configuration_is_bitwise_the_single_slot_engine(blob, onet,
         assert np.array_equal(raws[s]["boxes"], exp["boxes"])
 
 
+def test_synchronous_launch_form_is_reported_and_forced(blob, frame0, monkeypatch):
+    """A synchronous single-frame step has two launch forms (one hipGraph replay / kernel by kernel behind the upload): the engine
+    times both at creation and reports its choice (irmv_engine_sync_launch); IRMV_SYNC_LAUNCH forces one.  Same detections."""
+    got = {}
+    for forced in ("graph", "eager", None):
+        if forced:
+            monkeypatch.setenv("IRMV_SYNC_LAUNCH", forced)
+        else:
+            monkeypatch.delenv("IRMV_SYNC_LAUNCH", raising=False)
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=3) as e:
+            assert e.sync_launch in ("graph", "eager")
+            if forced:
+                assert e.sync_launch == forced
+            _load(e, 1, frame0)
+            e.detect(1)
+            e.detect(1)
+            got[forced] = (_raw_tuple(e.read_raw(1)), e.read_head(1).copy())
+    for k in ("eager", None):
+        assert got[k][0][0] == got["graph"][0][0] and all(np.array_equal(x, y) for x, y in zip(got[k][0][1:], got["graph"][0][1:]))
+        assert np.array_equal(got[k][1], got["graph"][1])
+
+
 def test_two_engines_with_independent_lifetimes(blob, frame0):
     """The reference node owns three engines (src/irm_detector.cpp:35-38): create A, create and destroy B, then A must
     still replay its graphs (upload included) and give the same bits."""
