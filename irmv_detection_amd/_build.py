@@ -21,6 +21,7 @@ SOURCES = [
     ("k_front.hip", []),
     ("k_c2f.hip", []),
     ("k_bneck.hip", []),
+    ("k_kpt.hip", []),
     ("k_conv.hip", []),
     ("k_post.hip", ["-ffp-contract=off"]),
     ("k_light.hip", ["-ffp-contract=off"]),

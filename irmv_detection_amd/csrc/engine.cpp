@@ -149,7 +149,7 @@ struct Tensor {
 
 struct SegRef { int t = -1, coff = 0, C = 0, shift = 0; };
 
-enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2, OP_C2F32, OP_DW, OP_SHUF, OP_SCAN, OP_BNECK };
+enum OpKind { OP_PRE, OP_CONV0, OP_CONV, OP_POOL, OP_NMS, OP_LIGHT, OP_FRONT, OP_C2F2, OP_C2F32, OP_DW, OP_SHUF, OP_SCAN, OP_BNECK, OP_KPT3 };
 
 struct Op {
     OpKind kind;
@@ -179,6 +179,7 @@ struct Op {
     bool fused_away = false;   // preprocess / model.0 / model.1 when the fused front kernel runs them (kept for read-backs)
     int group = -1;            // single-frame steps: index into irmv_engine::head_groups of the one launch this conv rides in
     int bneck = -1;            // single-frame steps: index of the OP_BNECK launch (k_bneck.hip) that computes this conv; OP_BNECK itself: 1 = kept
+    int kpt3 = -1;             // a keypoint-branch conv: index of the OP_KPT3 launch (k_kpt.hip) that computes its level's branch in every step; OP_KPT3 itself: 1
 };
 
 struct GraphKey {
@@ -274,6 +275,7 @@ struct irmv_engine {
     std::vector<std::vector<float>> merged_b;
     bool bneck64 = true;       // single-frame steps run the 64-channel Bottlenecks of the C2f blocks (and their cv2) as one launch each (IRMV_BNECK64=0: off)
     bool merge_head0 = false;
+    bool kpt3 = true;          // the keypoint branch of a Detect level as one launch (engines that do not merge the first-stage Detect convs; IRMV_KPT3=0: off)
 
     ~irmv_engine();
 };
@@ -672,6 +674,41 @@ static int fuse_bneck64(irmv_engine *e, const std::string &prefix, int n, bool s
     return IRMV_OK;                                 //  read-backs of them run the layer ops, like the fused 32-channel blocks')
 }
 
+// The keypoint branch of a Detect level -- the last three ops: 3x3 (Cin -> 16), 3x3 (16 -> 16) carrying the final 1x1 -- as one
+// launch (k_kpt.hip).  The OP_KPT3 op stands behind the layer ops; a step runs it and skips them, read-backs of the two
+// intermediate tensors run the layers (they remain the bit-exactness reference, IRMV_KPT3=0 the switch).
+static int fuse_kpt3(irmv_engine *e, int level)
+{
+    if (!e->kpt3 || e->ops.size() < 3) return IRMV_OK;
+    const int i2 = (int)e->ops.size() - 1, i1 = i2 - 1, i0 = i2 - 2;
+    const Op &o0 = e->ops[i0], &o1 = e->ops[i1], &o2 = e->ops[i2];
+    const bool ok = o0.kind == OP_CONV && o1.kind == OP_CONV && o2.kind == OP_CONV && o1.fuse_next == i2 && o1.cfg.cin16 && o2.w_k16 &&
+                    o0.cfg.ks == 3 && o0.cfg.stride == 1 && o0.cfg.act == 1 && !o0.cfg.out_f32 && !o0.cfg.cin16 && o0.cout_pad == 16 && !o0.pair && o0.res_t < 0 &&
+                    o0.s1.C == 0 && o0.s0.shift == 0 && o0.w_lds[0] != nullptr && kpt3_eligible(o0.cin) && o1.s0.t == o0.out_t && o1.cin == 16 && o1.ksteps == 5 &&
+                    o0.Hin == o1.Hin && o0.Win == o1.Win;
+    if (!ok) return IRMV_OK;
+    Op op;
+    op.kind = OP_KPT3;
+    op.layer = "model.22.cv4." + std::to_string(level) + " (one launch)";
+    snprintf(op.kname, sizeof op.kname, "kpt3_c%d", o0.cin);
+    snprintf(op.kname_one, sizeof op.kname_one, "%s", op.kname);
+    op.sub[0] = i0; op.sub[1] = i1; op.sub[2] = i2;
+    op.Hin = op.Hout = o0.Hin; op.Win = op.Wout = o0.Win;
+    op.cin = o0.cin;
+    op.lane = o0.lane; op.level = level;
+    op.flops = o0.flops + o1.flops + o2.flops;
+    op.w_bytes = o0.w_bytes + o1.w_bytes + o2.w_bytes;
+    op.out_bytes = o2.out_bytes;
+    op.bytes = op.w_bytes + (o0.bytes - o0.w_bytes - o0.out_bytes) + o2.out_bytes;   // the level's input once, the head's keypoint channels once
+    op.kpt3 = 1;
+    e->lazy_tensors.insert(e->tensors[o0.out_t].name);
+    e->lazy_tensors.insert(e->tensors[o1.out_t].name);
+    e->ops.push_back(op);
+    const int me = (int)e->ops.size() - 1;
+    e->ops[i0].kpt3 = e->ops[i1].kpt3 = e->ops[i2].kpt3 = me;
+    return IRMV_OK;
+}
+
 static int add_c2f(irmv_engine *e, const std::string &prefix, SegRef s0, SegRef s1, int H, int W, int c2, int n,
                    bool shortcut, int out_t)
 {
@@ -764,6 +801,7 @@ static int build_engine(irmv_engine *e)
     e->num_streams = c.num_streams > 0 ? c.num_streams : (c.num_slots <= 4 ? c.num_slots : std::min(4, std::max(2, (c.num_slots + 127) / 128)));   // batched: two graphs of up to 128 frames (round 3: with the
                                                                                                                                                    // weights-resident / multi-block kernels larger graphs win: 256 frames as 2 x 128 +6 % over 192 as 3 x 64)
     { const char *bn = getenv("IRMV_BNECK64"); e->bneck64 = !(bn && bn[0] == '0'); }   // (read before the op list is built)
+    { const char *kp = getenv("IRMV_KPT3"); e->kpt3 = !(kp && kp[0] == '0'); }
     if (const char *ns = getenv("IRMV_STREAMS")) e->num_streams = atoi(ns);
     e->num_streams = std::max(1, std::min({e->num_streams, 8, c.num_slots}));
     for (int i = 1; i < e->num_streams; i++) HIP_TRY(hipStreamCreateWithFlags(&e->extra_streams[i - 1], hipStreamNonBlocking));
@@ -1049,6 +1087,7 @@ static int build_engine(irmv_engine *e)
                 if (!(fh && fh[0] == '0') && o1.cfg.cin16 && o1.cout_pad == 16 && !o1.pair && o1.res_t < 0 && o1.cfg.stride == 1 && o1.cfg.act == 1 && o2.w_k16)
                     e->ops[i1].fuse_next = i2;
             }
+            if (b == 2 && !e->merge_head0) TRY(fuse_kpt3(e, i));
         }
 
     // ---- post-processing buffers ----
@@ -1995,7 +2034,9 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
         // single-frame steps: the 64-channel Bottlenecks ride in their OP_BNECK launch; every other step runs the layers
         const bool one_frame = count == 1 && !materialize && !post_only && e->bneck64;
         if (op.kind == OP_BNECK ? !one_frame : (op.bneck >= 0 && one_frame)) continue;
-        if (materialize ? !(op.fused_away || op.fuse_next >= 0 || (op.bneck >= 0 && op.kind == OP_CONV)) : op.fused_away) continue;
+        const bool fused_kpt = !materialize && !post_only;   // every step runs a level's keypoint branch as its OP_KPT3 launch (where the engine has one)
+        if (op.kind == OP_KPT3 ? !fused_kpt : (op.kpt3 >= 0 && fused_kpt)) continue;
+        if (materialize ? !(op.fused_away || op.fuse_next >= 0 || ((op.bneck >= 0 || op.kpt3 >= 0) && op.kind == OP_CONV)) : op.fused_away) continue;
         hipStream_t s = e->enq_stream ? e->enq_stream : e->stream;
         EvRec r{};
         r.op = (int)(&op - e->ops.data());
@@ -2073,6 +2114,20 @@ static int enqueue_step(irmv_engine *e, int first, int count, uint32_t flags, bo
                 ks2 = c2.ksteps;
             }
             if (!launch_bneck64(op.mode, ks2, op.shortcut, a, count, s)) return fail(IRMV_ERR_ARG, "no fused bottleneck kernel for " + op.layer);
+            break;
+        }
+        case OP_KPT3: {
+            const Op &o0 = e->ops[op.sub[0]], &o1 = e->ops[op.sub[1]], &o2 = e->ops[op.sub[2]];
+            const Tensor &xt = e->tensors[o0.s0.t], &ht = e->tensors[o2.out_t];
+            Kpt3Args a{};
+            a.x = static_cast<const half_t *>(xt.slot(first)) + o0.s0.coff; a.x_ld = xt.C;
+            a.H = op.Hin; a.W = op.Win;
+            a.tiles_x = (op.Win + kKpt3Tile - 1) / kKpt3Tile; a.tiles_y = (op.Hin + kKpt3Tile - 1) / kKpt3Tile;
+            a.w1 = o0.w_lds[0]; a.b1 = o0.bias;
+            a.w2 = o1.w_packed; a.b2 = o1.bias;
+            a.w3 = o2.w_k16; a.b3 = o2.bias;
+            a.out = static_cast<float *>(ht.slot(first)) + o2.out_coff; a.out_ld = ht.C;
+            if (!launch_kpt3(a, op.cin, count, s)) return fail(IRMV_ERR_ARG, "no fused keypoint-branch kernel for " + op.layer);
             break;
         }
         case OP_DW: {

@@ -241,6 +241,24 @@ struct BneckArgs {
 size_t bneck64_lds_bytes(int mode, int ks2);
 bool launch_bneck64(int mode, int ks2, bool shortcut, const BneckArgs &a, int batch, hipStream_t s);   // mode 0: A (-> concat slice), 1: B (+ cv2, ks2 = 6 / 8)
 
+// the keypoint branch of one Detect level (3x3 Cin -> 16, 3x3 16 -> 16, 1x1 16 -> nk) in one launch (k_kpt.hip)
+constexpr int kKpt3Tile = 10;
+struct Kpt3Args {
+    const half_t *x;      // the level's input [B][H][W][x_ld], offset to the first of its Cin channels
+    int x_ld;
+    int H, W, tiles_x, tiles_y;
+    const half_t *w1;     // first conv: LDS-family nt = 1 packing [chunk of 32][tap][64 lanes][8]
+    const float *b1;
+    const half_t *w2;     // second conv: Cin = 16 direct packing [5 k-steps][64 lanes][8]
+    const float *b2;
+    const half_t *w3;     // final 1x1: A layout of v_mfma_f32_16x16x16_f16 [64 lanes][4]
+    const float *b3;      // (not scaled: the final has no activation)
+    float *out;           // head records [B][H * W][out_ld], offset to the keypoint channels
+    int out_ld;
+};
+bool kpt3_eligible(int cin);
+bool launch_kpt3(const Kpt3Args &a, int cin, int batch, hipStream_t s);
+
 struct ConvArgs {
     ConvSeg s0, s1;
     int Hin, Win;       // input size at the conv's own resolution

@@ -665,7 +665,7 @@ def test_resident_weight_kernels_are_bitwise_the_chunked_ones(blob, monkeypatch,
 @pytest.mark.parametrize("switch", ["IRMV_INLINE_COPIES=1", "IRMV_ZERO_COPY_RESULTS=0", "IRMV_SPLIT_SCAN=0", "IRMV_EMIT_SCAN=0",
                                     "IRMV_FUSED_HEAD=0", "IRMV_MERGE_HEAD0=0", "IRMV_GROUP_HEAD=0", "IRMV_NO_PF2=1", "IRMV_NO_DEEP=1",
                                     "IRMV_FRONT_FASTX=0", "IRMV_FRONT_DIRECT=0", "IRMV_FRONT_TILE8=0",
-                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1", "IRMV_NMS_CLASSWALK=0", "IRMV_NO_PF4=1", "IRMV_WRES_STAGGER=0", "IRMV_BNECK64=0", "IRMV_UPLOAD_KERNEL=0", "IRMV_SYNC_LAUNCH=graph", "IRMV_SYNC_LAUNCH=eager"])
+                                    "IRMV_STREAMS=1", "IRMV_AUTOTUNE=0", "IRMV_GROUP_FORCE=1", "IRMV_NUMA=0", "IRMV_GRAPH_UPLOAD=0", "IRMV_XCD_IMAGES=0", "IRMV_NO_NT8=1", "IRMV_NMS_CLASSWALK=0", "IRMV_NO_PF4=1", "IRMV_WRES_STAGGER=0", "IRMV_BNECK64=0", "IRMV_KPT3=0", "IRMV_UPLOAD_KERNEL=0", "IRMV_SYNC_LAUNCH=graph", "IRMV_SYNC_LAUNCH=eager"])
 def test_every_remaining_switch_is_bitwise_the_default(blob, monkeypatch, switch):
     """The environment switches that select between implementations of the same arithmetic (where the copies ride, where the
     results land, where candidates are found, which launches are merged): heads and detections of a batched step, of
@@ -819,6 +819,39 @@ def test_single_frame_bottleneck_kernels_are_bitwise_the_layers(blob, monkeypatc
             else:
                 assert np.array_equal(x, y), net
     monkeypatch.delenv("IRMV_BNECK64")
+
+
+def test_keypoint_branch_kernel_is_bitwise_the_layers(blob, monkeypatch):
+    """Engines that keep the Detect branches' convs apart (every batched engine) run a level's keypoint branch -- 3x3 (Cin -> 16),
+    3x3 (16 -> 16), final 1x1 -- as one launch (k_kpt.hip: 6 launches -> 3).  Same rounding points and K order as the layer
+    kernels: head, detections and keypoints are theirs bit for bit at a 640 net (80 / 40 / 20 maps: whole 10 x 10 tiles) and a
+    416 net (52 / 26 / 13: partial tiles on two sides), in a batched step and a step of one frame of the same engine;
+    read-backs of the branch's internal tensors still run the layers."""
+    for net in (640, 416):
+        outs = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("IRMV_KPT3", mode)
+            with YoloEngine(None, (1280, 1024), weights_blob=blob, net_size=net, num_slots=6, point_source=capi.POINTS_AUTO) as e:
+                prof = e.profile(0, 6)
+                names = [st["name"] for st in prof]
+                assert sorted(n for n in names if n.startswith("kpt3_c")) == (["kpt3_c128", "kpt3_c256", "kpt3_c64"] if mode == "1" else []), names
+                assert any(st["layer"] == "model.22.cv4.0.0" for st in prof) == (mode == "0")
+                for s in range(6):
+                    _load(e, s, frames.synthetic_frame(5 + s))
+                e.submit(0, 6); e.wait()                     # (six slots: two streams of three -- a batched engine; up to four slots are single-frame engines)
+                got = [e.read_head(s).copy() for s in range(6)] + [_raw_tuple(e.read_raw(s)) for s in range(6)]
+                got += [e.read_tap(t, 1).copy() for t in ("22.cv4.0.0", "22.cv4.1.1", "22.cv4.2.0")]   # internal tensors: materialised by the layer ops
+                e.detect(1)                                  # a step of one frame on the same engine ...
+                got.append(e.read_head(1).copy())
+                assert np.array_equal(got[1], got[-1])       # ... equals the batched step
+                outs.append(got)
+        for x, y in zip(*outs):
+            if isinstance(x, tuple):
+                assert x[0] == y[0] and all(np.array_equal(p, q) for p, q in zip(x[1:], y[1:])), net
+            else:
+                assert np.array_equal(x, y), net
+        assert np.abs(outs[0][0][:, 80:88]).max() > 0        # (the keypoint channels are populated)
+    monkeypatch.delenv("IRMV_KPT3")
 
 
 def test_grouped_detect_launches_are_bitwise_the_separate_convs(blob, monkeypatch):
