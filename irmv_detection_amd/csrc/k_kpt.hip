@@ -48,8 +48,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // STEPS = Cin / 64 (1, 2, 4).  A workgroup keeps its tile for `ipw` consecutive images: the slab of the next (image, slab) step
 // is on its way while this one's MFMAs run, stage 1's fragments are fetched once (Cin = 64: all 18 in registers for the
 // workgroup's lifetime) or ride a ring that runs on across images.
-template <int STEPS, bool AREG = false>
-__global__ __launch_bounds__(KNT) __attribute__((amdgpu_waves_per_eu(AREG ? 2 : 3))) void kpt3_kernel(Kpt3Args a, int batch, int ipw, int xcd)
+template <int STEPS>
+__global__ __launch_bounds__(KNT) __attribute__((amdgpu_waves_per_eu(3))) void kpt3_kernel(Kpt3Args a, int batch, int ipw, int xcd)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_in = smem;                  // one 64-channel slab of the input region, zero outside the image (= the 3x3's padding)
@@ -108,10 +108,9 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_waves_per_eu(AREG ? 2 : 
     // what stages 2 and 3 will want ----
     issue_slab();
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int NA = AREG ? 18 : 6;
-    half8 A[NA];
+    half8 A[6];   // (Cin = 64 with all 18 fragments in registers for the workgroup's lifetime: 205 VGPRs, two waves per SIMD, 8 % slower)
 #pragma unroll
-    for (int k = 0; k < NA; k++) A[k] = load_w(k);
+    for (int k = 0; k < 6; k++) A[k] = load_w(k);
     const f32x4 b1 = *reinterpret_cast<const f32x4 *>(a.b1 + g * 4);
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -152,23 +151,20 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_waves_per_eu(AREG ? 2 : 
             write_slab();
             __syncthreads();
             frag(0, Bf[0]);
-            if constexpr (AREG) issue_slab();   // (nothing else is requested during the step: the next slab has the whole step to arrive)
 #pragma unroll
             for (int kk = 0; kk < 18; kk++) {
                 const int k = s * 18 + kk;
                 if (kk + 1 < 18) frag(kk + 1, Bf[(kk + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 3; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[AREG ? k : kk % 6], Bf[kk & 1][i], acc[i], 0, 0, 0);
+                for (int i = 0; i < 3; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[kk % 6], Bf[kk & 1][i], acc[i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!AREG) {
-                    // the next slab's loads go out BEHIND the fragments this slab still needs and in front of the next slab's
-                    // first six: a fragment requested after them waits for them (in-order counter), and those six are not
-                    // needed before the slab itself is.  The ring runs on across slabs and images (k wraps).
-                    if (kk == 12) issue_slab();
-                    A[kk % 6] = load_w((k + 6) % KSTEPS);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                // the next slab's loads go out BEHIND the fragments this slab still needs and in front of the next slab's
+                // first six: a fragment requested after them waits for them (in-order counter), and those six are not
+                // needed before the slab itself is.  The ring runs on across slabs and images (k wraps).
+                if (kk == 12) issue_slab();
+                A[kk % 6] = load_w((k + 6) % KSTEPS);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (s + 1 < STEPS) __syncthreads();   // every wave is done reading the slab (the last slab: the barrier behind the epilogue)
         }
@@ -218,17 +214,13 @@ bool launch_kpt3(const Kpt3Args &a, int cin, int batch, hipStream_t s)
     // start does not.  Measured at 128 frames: 80 x 80 level 61.8 / 54.7 / 53.1 / 50.6 us at 1 / 2 / 4 / 8, 20 x 20 level 13.4 / 16.4 / 26.7.
     const int tiles = a.tiles_x * a.tiles_y;
     int ipw = 1;
-    if (const char *v = getenv("IRMV_KPT3_IPW")) ipw = atoi(v) > 0 ? atoi(v) : 1;
-    else while (ipw < 8 && (long long)tiles * batch >= 2048LL * ipw) ipw *= 2;
+    while (ipw < 8 && (long long)tiles * batch >= 2048LL * ipw) ipw *= 2;
     const dim3 grid(tiles * ((batch + ipw - 1) / ipw)), block(KNT);
     constexpr size_t lds = (size_t)2 * KPL + (size_t)K2N * KQS + 4608;   // 34 304 bytes: four workgroups per CU
     static_assert(lds <= 40 * 1024, "four workgroups per CU");
     const int xcd = xcd_image_order();
     switch (cin) {
-    case 64:
-        if (getenv("IRMV_KPT3_AREG")) hipLaunchKernelGGL((kpt3_kernel<1, true>), grid, block, lds, s, a, batch, ipw, xcd);
-        else hipLaunchKernelGGL((kpt3_kernel<1>), grid, block, lds, s, a, batch, ipw, xcd);
-        return true;
+    case 64: hipLaunchKernelGGL((kpt3_kernel<1>), grid, block, lds, s, a, batch, ipw, xcd); return true;
     case 128: hipLaunchKernelGGL((kpt3_kernel<2>), grid, block, lds, s, a, batch, ipw, xcd); return true;
     case 256: hipLaunchKernelGGL((kpt3_kernel<4>), grid, block, lds, s, a, batch, ipw, xcd); return true;
     default: return false;

@@ -26,6 +26,12 @@ def internal_name(sym):
     m = re.search(r"c2f32_kernel<(\d), (\d), (true|false)(?:, \d+)?>", sym)
     if m:
         return {"0": "c2f32_ab", "1": "c2f32_a", "2": "c2f32_b"}[m.group(1)]
+    m = re.search(r"kpt3_kernel<(\d)>", sym) or re.search(r"kpt3_kernelILi(\d)E", sym)
+    if m:   # the keypoint branch of a Detect level in one launch (round 5): <Cin / 64>
+        return f"kpt3_c{64 * int(m.group(1))}"
+    m = re.search(r"bneck64_kernel<(\d), (\d), (true|false)>", sym) or re.search(r"bneck64_kernelILi(\d)ELi(\d)ELb([01])E", sym)
+    if m:
+        return "bneck64_b" if m.group(1) == "1" else "bneck64_a"
     for k, v in (("front_kernel", "front_fused"), ("c2f2_kernel", "c2f2_fused"), ("light_extract_kernel", "light_extract"), ("preprocess_kernel", "preprocess"), ("conv0_kernel", "conv0_mfma"), ("sppf_pool", "sppf_pool"), ("decode_kernel", "decode"), ("nms_pnp_kernel", "nms_pnp")):
         if k in sym:
             return v
