@@ -687,6 +687,10 @@ static int fuse_kpt3(irmv_engine *e, int level)
                     o0.s1.C == 0 && o0.s0.shift == 0 && o0.w_lds[0] != nullptr && kpt3_eligible(o0.cin) && o1.s0.t == o0.out_t && o1.cin == 16 && o1.ksteps == 5 &&
                     o0.Hin == o1.Hin && o0.Win == o1.Win;
     if (!ok) return IRMV_OK;
+    {   // the kernel addresses the level's input through a buffer descriptor with 32-bit byte offsets
+        const Tensor &xt = e->tensors[o0.s0.t];
+        if ((double)e->cfg.num_slots * xt.H * xt.W * xt.C * 2.0 >= 2147483648.0) return IRMV_OK;
+    }
     Op op;
     op.kind = OP_KPT3;
     op.layer = "model.22.cv4." + std::to_string(level) + " (one launch)";

@@ -49,7 +49,7 @@ for k, c in sorted(acc.items()):
         d["lds_conflict_share"] = round(per.get("SQ_LDS_BANK_CONFLICT", 0.0) / per["SQ_LDS_IDX_ACTIVE"], 4)
     d["raw_per_launch"] = {name: round(v, 1) for name, v in sorted(per.items())}
     out[k] = d
-    if mf is not None and cu and (k.startswith("conv") or k in ("front_fused", "c2f2_fused") or k.startswith("c2f")):
+    if mf is not None and cu and (k.startswith("conv") or k in ("front_fused", "c2f2_fused") or k.startswith("c2f") or k.startswith("kpt3") or k.startswith("bneck64")):
         tot_busy += mf * n
         tot_cu += cu * n
 from build_stamp import build_stamp  # noqa: E402
