@@ -851,7 +851,24 @@ def test_keypoint_branch_kernel_is_bitwise_the_layers(blob, monkeypatch):
             else:
                 assert np.array_equal(x, y), net
         assert np.abs(outs[0][0][:, 80:88]).max() > 0        # (the keypoint channels are populated)
+    # A workgroup keeps its tile for several consecutive images once a launch has >= 2048 tile-images (80 x 80 level: from 32
+    # frames per stream), and deals image groups to XCDs in eights: 74 slots = two streams of 37 frames -> two images per
+    # workgroup, 19 groups (a last group of one image, three groups behind the whole eights); with and without the XCD order.
+    heads = {}
+    for mode, xcd in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("IRMV_KPT3", mode)
+        monkeypatch.setenv("IRMV_XCD_IMAGES", xcd)
+        with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=74, point_source=capi.POINTS_AUTO) as e:
+            for s in range(74):
+                _load(e, s, frames.synthetic_frame(200 + (s % 9)))
+            e.submit(0, 74); e.wait()
+            heads[(mode, xcd)] = [e.read_head(s)[:, 80:88].copy() for s in range(74)]
+    for s in range(74):
+        assert np.array_equal(heads[("1", "1")][s], heads[("0", "1")][s]), s
+        assert np.array_equal(heads[("1", "0")][s], heads[("0", "1")][s]), s
+        assert np.array_equal(heads[("1", "1")][s], heads[("1", "1")][s % 9]), s     # (slots s and s % 9 hold the same frame)
     monkeypatch.delenv("IRMV_KPT3")
+    monkeypatch.delenv("IRMV_XCD_IMAGES")
 
 
 def test_grouped_detect_launches_are_bitwise_the_separate_convs(blob, monkeypatch):
