@@ -182,7 +182,10 @@ void *irmv_engine_src_device_buffer(irmv_engine *e, int slot);
  * With IRMV_SUBMIT_ASYNC_UPLOAD the upload rides a side stream -- the dGPU form of the reference's TripleBuffer
  * hand-off (triple_buffer.hpp:24-40, src/camera.cpp:40-61): submit slot n+1 while slot n is in flight, collect each
  * with irmv_engine_wait_slots().  count == 1 is the reference's per-slot detect(); count > 1 batches independent
- * frames through every kernel.  One thread submits. */
+ * frames through every kernel.  One thread submits.
+ * A multi-slot step is cut into one sub-batch (one captured graph) per compute stream of the engine; a submit of exactly
+ * one stream's share of the engine's slots, aligned to it (e.g. slots [128, 256) of a 256-slot, two-stream engine), IS
+ * that sub-batch -- the same graph on the same stream -- so a producer may feed the shares separately. */
 int irmv_engine_submit(irmv_engine *e, int first_slot, int count, uint32_t flags);
 /* Block until everything submitted so far is done and host-visible. */
 int irmv_engine_wait(irmv_engine *e);

@@ -2345,10 +2345,15 @@ extern "C" int irmv_engine_submit(irmv_engine *e, int first, int count, uint32_t
     // A multi-slot step is cut into num_streams independent sub-batches, one captured graph each, on
     // separate streams: while one sub-batch sits in a launch gap or a kernel tail the other keeps the
     // CUs busy (two sub-batches measured +30 % frames/s over one stream at 32 frames).
-    const int share = count > 1 ? stream_share(e, count) : count;
+    int share = count > 1 ? stream_share(e, count) : count;
     // Single-slot steps ride the compute stream of their slot (slot mod num_streams): a single frame fills a fraction of
     // the chip, so the steps of two slots in flight (the TripleBuffer's depth) overlap instead of queueing behind each other.
     int si = count == 1 ? first % e->num_streams : 0;
+    // A submit of exactly ONE stream's share of the engine's slots, aligned to it, is that share's sub-batch of a whole-engine
+    // step: the same captured graph on the same stream.  A caller that feeds the shares separately decides itself how far
+    // apart the streams run (two shares started together execute the same kernel at the same time all the way down).
+    const int full_share = stream_share(e, e->cfg.num_slots);
+    if (count > 1 && count == full_share && first % full_share == 0 && first / full_share < e->num_streams) { share = count; si = first / full_share; }
     for (int f = first; f < first + count; f += share, si++) {
         const int c = std::min(share, first + count - f);
         hipStream_t st = si == 0 ? e->stream : e->extra_streams[si - 1];

@@ -821,6 +821,28 @@ def test_single_frame_bottleneck_kernels_are_bitwise_the_layers(blob, monkeypatc
     monkeypatch.delenv("IRMV_BNECK64")
 
 
+def test_a_stream_share_submitted_alone_is_its_sub_batch_of_the_whole_step(blob):
+    """A multi-slot step is one captured graph per compute stream; a submit of exactly one stream's share of the slots is that
+    sub-batch (same graph, same stream): feeding the two shares of a six-slot engine separately, in either order and with the
+    second one late, gives the whole step's heads and detections (scripts/probes/phase_probe.py feeds a benchmark this way)."""
+    with YoloEngine(None, (1280, 1024), weights_blob=blob, num_slots=6) as e:
+        for s in range(6):
+            _load(e, s, frames.synthetic_frame(40 + s))
+        e.submit(0, 6); e.wait()
+        want = [e.read_head(s).copy() for s in range(6)] + [_raw_tuple(e.read_raw(s)) for s in range(6)]
+        for order in ((0, 3), (3, 0)):
+            e.submit(order[0], 3); e.wait_slots(order[0], 3)
+            e.submit(order[1], 3); e.wait()
+            got = [e.read_head(s).copy() for s in range(6)] + [_raw_tuple(e.read_raw(s)) for s in range(6)]
+            for a, b in zip(want, got):
+                if isinstance(a, tuple):
+                    assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+                else:
+                    assert np.array_equal(a, b)
+        names = [st["name"] for st in e.profile(3, 3)]
+        assert len(names) > 10
+
+
 def test_keypoint_branch_kernel_is_bitwise_the_layers(blob, monkeypatch):
     """Engines that keep the Detect branches' convs apart (every batched engine) run a level's keypoint branch -- 3x3 (Cin -> 16),
     3x3 (16 -> 16), final 1x1 -- as one launch (k_kpt.hip: 6 launches -> 3).  Same rounding points and K order as the layer
