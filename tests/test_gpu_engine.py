@@ -848,8 +848,8 @@ def test_keypoint_branch_kernel_is_bitwise_the_layers(blob, monkeypatch):
     3x3 (16 -> 16), final 1x1 -- as one launch (k_kpt.hip: 6 launches -> 3).  Same rounding points and K order as the layer
     kernels: head, detections and keypoints are theirs bit for bit at a 640 net (80 / 40 / 20 maps: whole 10 x 10 tiles) and a
     416 net (52 / 26 / 13: partial tiles on two sides), in a batched step and a step of one frame of the same engine;
-    read-backs of the branch's internal tensors still run the layers."""
-    for net in (640, 416):
+    read-backs of the branch's internal tensors still run the layers.  A 320 net has a 10 x 10 top level: one tile per image."""
+    for net in (640, 416, 320):
         outs = []
         for mode in ("1", "0"):
             monkeypatch.setenv("IRMV_KPT3", mode)
